@@ -1,0 +1,141 @@
+"""ctypes binding of include/adcraft_engine.h (the C ABI of the HIP engine).
+
+No PyTorch, no fallbacks: if the shared library is missing and cannot be built, or if no HIP
+device is usable, the error is raised to the caller.  ctypes releases the GIL during calls.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+ADC_OK, ADC_EINVAL, ADC_EHIP, ADC_ENOMEM, ADC_ESTATE, ADC_ETYPE = 0, -1, -2, -3, -4, -5
+MODEL_IMPLICIT, MODEL_EXPLICIT = 0, 1
+P_VOL_MEAN, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT = range(9)
+(BUF_PARAMS, BUF_BIDS, BUF_BUDGET, BUF_IMPRESSIONS, BUF_CLICKS, BUF_CONVERSIONS, BUF_COST, BUF_REVENUE, BUF_REWARD,
+ BUF_CUM_PROFIT, BUF_DAYS, BUF_TERMINATED, BUF_TRUNCATED, BUF_METRIC_PROFIT, BUF_METRIC_SCALARS, BUF_FLAT_OBS) = range(16)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device_id", C.c_int32), ("num_envs", C.c_int32),
+                ("num_keywords", C.c_int32), ("model", C.c_int32), ("max_days", C.c_int32),
+                ("loss_threshold", C.c_double), ("drift_vol", C.c_float), ("drift_ctr", C.c_float),
+                ("drift_cvr", C.c_float), ("drift_enabled", C.c_int32), ("impression_thresh", C.c_float),
+                ("auto_reset", C.c_int32), ("env_id_base", C.c_int64), ("seed", C.c_uint64)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("impressions", "buyside_clicks", "sellside_conversions", "cost", "revenue",
+                                          "reward", "cumulative_profit", "days_passed", "terminated", "truncated")]
+
+
+class Tape(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("volumes", "bid_cents", "x_impressions", "x_cost", "click", "conv", "rev_cents")]
+                + [(n, C.c_int64) for n in ("len_bid", "len_ximp", "len_xcost", "len_click", "len_conv", "len_rev")]
+                + [(n, C.c_void_p) for n in ("off_bid", "off_ximp", "off_xcost", "off_click", "off_conv", "off_rev")]
+                + [(n, C.c_void_p) for n in ("end_bid", "end_ximp", "end_xcost", "end_click", "end_conv", "end_rev")])
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load (building in-tree first if needed) libadcraft_hip.so; raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path) or _build.stale():
+        try:
+            _build.build()
+        except Exception as exc:  # no hipcc / compile error: there is nothing to fall back to
+            if not os.path.exists(path):
+                raise EngineError(f"HIP engine library {path} is missing and could not be built: {exc}") from exc
+    L = C.CDLL(path)
+    L.adc_last_error.restype = C.c_char_p
+    vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+    sig = {
+        "adc_abi_version": ([], C.c_int),
+        "adc_device_count": ([vp], C.c_int),
+        "adc_engine_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
+        "adc_engine_destroy": ([vp], None),
+        "adc_engine_set_params": ([vp, C.c_int, vp], C.c_int),
+        "adc_engine_get_params": ([vp, C.c_int, vp], C.c_int),
+        "adc_engine_set_env_params": ([vp, C.c_int, vp], C.c_int),
+        "adc_engine_reset": ([vp, vp, vp], C.c_int),
+        "adc_engine_get_rng_state": ([vp, vp, vp], C.c_int),
+        "adc_engine_set_rng_state": ([vp, vp, vp], C.c_int),
+        "adc_engine_get_episode_state": ([vp, vp, vp], C.c_int),
+        "adc_engine_set_episode_state": ([vp, vp, vp], C.c_int),
+        "adc_engine_step": ([vp, vp, vp, C.POINTER(StepOut)], C.c_int),
+        "adc_engine_step_device": ([vp, vp, vp], C.c_int),
+        "adc_engine_fetch": ([vp, C.POINTER(StepOut)], C.c_int),
+        "adc_engine_synchronize": ([vp], C.c_int),
+        "adc_engine_step_replay": ([vp, vp, vp, C.POINTER(Tape), C.POINTER(StepOut)], C.c_int),
+        "adc_engine_update_keywords": ([vp], C.c_int),
+        "adc_engine_device_buffer": ([vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)], C.c_int),
+        "adc_engine_stream": ([vp, C.POINTER(vp)], C.c_int),
+        "adc_engine_sample_actions": ([vp, f32, f32, f32], C.c_int),
+        "adc_engine_set_flat_actions_device": ([vp, vp], C.c_int),
+        "adc_engine_profile_enable": ([vp, C.c_int], C.c_int),
+        "adc_engine_profile_read": ([vp, C.POINTER(f64), C.POINTER(i64)], C.c_int),
+        "adc_engine_metrics_enable": ([vp, C.c_int], C.c_int),
+        "adc_engine_metrics_reset": ([vp], C.c_int),
+        "adc_engine_metrics_read": ([vp, vp, vp], C.c_int),
+        "adc_engine_ideal_profit": ([vp, C.c_int, vp], C.c_int),
+        "adc_nth_price_auction": ([C.c_int, f64, vp, i32, i32, i32, i32, C.POINTER(i32), vp, vp], C.c_int),
+        "adc_sigmoid": ([f64, f64, f64], f64),
+        "adc_clamp": ([f64, f64, f64], f64),
+        "adc_threshold_sigmoid": ([f64, f64, f64, f64], f64),
+        "adc_sum_f64": ([vp, i64], f64),
+        "adc_count_true": ([vp, i64], i64),
+        "adc_nonneg_int_normal": ([f64, f64, u64, u64], u64),
+        "adc_binomial": ([u64, f64, u64, u64], u64),
+        "adc_cost_create": ([f64, i64, u64, u64, vp], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)      # AttributeError here = the .so does not export what the header declares
+        fn.argtypes = args
+        fn.restype = res
+    if L.adc_abi_version() != 1:
+        raise EngineError("libadcraft_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED = None  # filled by tests from include/adcraft_engine.h
+
+
+def check(rc):
+    """Map adc_status to the exceptions the reference's callers see (SURVEY 8b error conventions)."""
+    if rc == ADC_OK:
+        return
+    msg = (lib().adc_last_error() or b"").decode("utf-8", "replace")
+    if rc == ADC_EINVAL:
+        raise ValueError(msg)
+    if rc == ADC_ESTATE:
+        raise AssertionError(msg)          # gymnasium_kw_env.py:194-196 asserts on step-before-reset
+    if rc == ADC_ENOMEM:
+        raise MemoryError(msg)
+    if rc == ADC_ETYPE:
+        raise TypeError(msg)
+    raise EngineError(msg)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().adc_device_count(C.byref(n))
+    return n.value if rc == ADC_OK else 0

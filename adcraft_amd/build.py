@@ -1,0 +1,50 @@
+"""Build the HIP engine for gfx950 in-tree: adcraft_amd/lib/libadcraft_hip.so.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off keeps every float32 rounding of
+csrc/adc_law.h a single IEEE operation (the CPU oracle reproduces them bit for bit);
+correctly rounded f32 divide/sqrt is hipcc's default and is requested explicitly.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC_DIR = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libadcraft_hip.so")
+SOURCES = ["adc_engine.hip", "adc_shims.cpp"]
+HEADERS = ["adc_law.h", os.path.join(ROOT, "include", "adcraft_engine.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+         "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _deps():
+    out = [os.path.join(SRC_DIR, s) for s in SOURCES]
+    out += [h if os.path.isabs(h) else os.path.join(SRC_DIR, h) for h in HEADERS]
+    return [p for p in out if os.path.exists(p)]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build(force=False, verbose=False, extra=()):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    if not force and not stale():
+        return LIB
+    srcs = [os.path.join(SRC_DIR, s) for s in SOURCES if os.path.exists(os.path.join(SRC_DIR, s))]
+    cmd = [HIPCC] + FLAGS + list(extra) + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,249 @@
+// adc_law.h - the engine's random stream and sampling law (gfx950 device code; the few scalar
+// FFI shims reuse it on the host).
+//
+// Stream: Philox4x32-10 (Salmon et al., SC11), counter-addressed, no per-lane state in HBM:
+//     words = philox(key = env key (64 bit), ctr = (index, stage, keyword, tick))
+// so a variate depends only on WHAT it is for - never on which lane, wave, block or GPU drew it.
+// Transforms are float32 and use only operations that IEEE-754 rounds correctly
+// (+ - * / sqrt fma rint), each written out explicitly (build with -ffp-contract=off), which is
+// what lets a CPU restatement reproduce every integer this file produces.
+//
+// What each transform stands for in the reference:
+//   laplace_cents    round2(max(|Laplace(loc,scale)|, 0))   adcraft/synthetic_kw_helpers.py:104-113
+//   bernoulli        rng.random(n) <= p                     adcraft/synthetic_kw_helpers.py:73-77
+//   revenue_cents    round2(max(N(mu,sd), 0.01))            adcraft/synthetic_kw_helpers.py:66-70
+//   volume           round(max(N(mean,sd), 0))              src/lib.rs:314-325
+//   explicit_cost    clamp(sqrt(x)/4 + 2.2 + N(0,.), 0, 4.4) src/lib.rs:54-67
+//   threshold_sigmoid                                        src/lib.rs:93-105
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ADC_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define ADC_HD static inline
+#endif
+
+namespace adc {
+
+enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6 };
+constexpr int kTimesteps = 24;          // adcraft/bidding_simulation.py:213
+constexpr int kVolumeMax = 1 << 20;
+constexpr float kMoneyMaxCents = 1.0e9f;
+
+struct U4 { uint32_t x, y, z, w; };
+
+ADC_HD void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+    const uint64_t a = (uint64_t)0xD2511F53u * c0;
+    const uint64_t b = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(b >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(a >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)b;
+    c3 = (uint32_t)a;
+    c0 = n0;
+    c2 = n2;
+}
+
+ADC_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+ADC_HD U4 draw(uint64_t key, uint32_t index, uint32_t stage, uint32_t keyword, uint32_t tick)
+{
+    return philox4x32_10(index, stage, keyword, tick, (uint32_t)key, (uint32_t)(key >> 32));
+}
+
+// ---- bit casts ---------------------------------------------------------------------------------
+ADC_HD float bits_to_float(uint32_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    union { uint32_t u; float f; } v; v.u = u; return v.f;
+#endif
+}
+ADC_HD uint32_t float_to_bits(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    union { uint32_t u; float f; } v; v.f = f; return v.u;
+#endif
+}
+ADC_HD float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ---- deterministic log / exp (Cephes single-precision schemes) ----------------------------------
+ADC_HD float det_log(float x)
+{
+    const uint32_t u = float_to_bits(x);
+    int e = (int)(u >> 23) - 126;
+    float m = bits_to_float((u & 0x007FFFFFu) | 0x3F000000u);       // [0.5, 1)
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292E-2f;
+    p = fma32(p, f, -1.1514610310E-1f);
+    p = fma32(p, f, 1.1676998740E-1f);
+    p = fma32(p, f, -1.2420140846E-1f);
+    p = fma32(p, f, 1.4249322787E-1f);
+    p = fma32(p, f, -1.6668057665E-1f);
+    p = fma32(p, f, 2.0000714765E-1f);
+    p = fma32(p, f, -2.4999993993E-1f);
+    p = fma32(p, f, 3.3333331174E-1f);
+    float y = f * (z * p);
+    const float fe = (float)e;
+    y = fma32(fe, -2.12194440e-4f, y);
+    y = fma32(z, -0.5f, y);
+    float r = f + y;
+    r = fma32(fe, 0.693359375f, r);
+    return r;
+}
+
+ADC_HD float det_exp(float x)
+{
+    x = x > 87.0f ? 87.0f : x;
+    x = x < -87.0f ? -87.0f : x;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fma32(n, -0.693359375f, x);
+    r = fma32(n, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500E-4f;
+    p = fma32(p, r, 1.3981999507E-3f);
+    p = fma32(p, r, 8.3334519073E-3f);
+    p = fma32(p, r, 4.1665795894E-2f);
+    p = fma32(p, r, 1.6666665459E-1f);
+    p = fma32(p, r, 5.0000001201E-1f);
+    const float y = fma32(p, z, r) + 1.0f;
+    return y * bits_to_float((uint32_t)((int)n + 127) << 23);
+}
+
+// ---- uniforms -----------------------------------------------------------------------------------
+ADC_HD float unit_open23(uint32_t w) { return ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f; }   // (0,1)
+ADC_HD float unit_half24(uint32_t w) { return ((float)(w >> 9) + 0.5f) * 5.9604644775390625e-08f; }   // (0,0.5)
+ADC_HD float unit_closed24(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }          // [0,1)
+ADC_HD bool sign_bit(uint32_t w) { return (w >> 8) & 1u; }
+
+// standard normal by inversion, Wichura AS241 PPND7; lower-tail probability from bits 31..9, sign = bit 8
+ADC_HD float normal_from_word(uint32_t w)
+{
+    const float p = unit_half24(w);
+    const float q = p - 0.5f;
+    float val;
+    if (q >= -0.425f) {
+        const float r = fma32(-q, q, 0.180625f);
+        const float num = fma32(fma32(fma32(5.9109374720e1f, r, 1.5929113202e2f), r, 5.0434271938e1f), r, 3.3871327179e0f);
+        const float den = fma32(fma32(fma32(6.7187563600e1f, r, 7.8757757664e1f), r, 1.7895169469e1f), r, 1.0f);
+        val = q * num / den;
+    } else {
+        const float r = __builtin_sqrtf(-det_log(p)) - 1.6f;
+        const float num = fma32(fma32(fma32(1.7023821103e-1f, r, 1.3067284816e0f), r, 2.7568153900e0f), r, 1.4234372777e0f);
+        const float den = fma32(fma32(1.2021132975e-1f, r, 7.3700164250e-1f), r, 1.0f);
+        val = -(num / den);
+    }
+    return sign_bit(w) ? -val : val;
+}
+
+ADC_HD int32_t money_to_cents(float dollars)
+{
+    float c = __builtin_rintf(dollars * 100.0f);
+    c = c < kMoneyMaxCents ? c : kMoneyMaxCents;
+    return (int32_t)c;
+}
+
+ADC_HD int32_t laplace_cents(uint32_t w, float loc, float scale)
+{
+    const float e = -det_log(unit_open23(w));
+    const float z = sign_bit(w) ? e : -e;
+    return money_to_cents(__builtin_fabsf(fma32(scale, z, loc)));
+}
+
+// event <=> (uint64)word < threshold; threshold = round(p * 2^32) in [0, 2^32]
+ADC_HD uint64_t bernoulli_threshold(float p)
+{
+    double t = __builtin_floor((double)p * 4294967296.0 + 0.5);
+    if (!(t > 0.0)) return 0;
+    if (t > 4294967296.0) t = 4294967296.0;
+    return (uint64_t)t;
+}
+ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < threshold; }
+
+ADC_HD int32_t revenue_cents(uint32_t w, float mu, float sd)
+{
+    float x = fma32(sd, normal_from_word(w), mu);
+    x = x > 0.01f ? x : 0.01f;
+    return money_to_cents(x);
+}
+
+ADC_HD int32_t volume_from_word(uint32_t w, float mean, float sd)
+{
+    float x = fma32(sd, normal_from_word(w), mean);
+    x = x > 0.0f ? x : 0.0f;
+    x = x < (float)kVolumeMax ? x : (float)kVolumeMax;
+    const float t = __builtin_truncf(x);
+    return (int32_t)t + ((x - t) >= 0.5f ? 1 : 0);          // f64::round: half away from zero
+}
+
+// action canonicalisation, adcraft/gymnasium_kw_env.py:199,215 (numpy round(x,2) == rint(x*100)/100 in f64)
+ADC_HD int64_t bid_to_cents(float bid)
+{
+    double c = __builtin_rint((double)bid * 100.0);
+    if (!(c >= 1.0)) c = 1.0;
+    if (c > 1.0e9) c = 1.0e9;
+    return (int64_t)c;
+}
+ADC_HD int64_t budget_to_cents(float budget)
+{
+    double c = __builtin_rint((double)budget * 100.0);
+    if (!(c > -9.0e15)) c = -9.0e15;
+    if (c > 9.0e15) c = 9.0e15;
+    return (int64_t)c;
+}
+
+ADC_HD float clamp01(float v) { v = v > 0.0f ? v : 0.0f; return v < 1.0f ? v : 1.0f; }
+
+ADC_HD float threshold_sigmoid_f32(float bid, float thresh, float intercept, float slope)
+{
+    const float th = clamp01(2.0f * thresh) / 2.0f;         // halver = 2 + 1e-10 rounds to 2.0f
+    const float r = 1.0f / (1.0f + det_exp(-slope * (bid - intercept)));
+    return clamp01(fma32(fma32(2.0f, th, 1.0f), r, -th));
+}
+
+ADC_HD float explicit_cost(uint32_t w, float bid)
+{
+    const float sq = __builtin_sqrtf(bid);
+    const float sd = 1e-10f + sq / 6.0f;
+    float v = fma32(sd, normal_from_word(w), sq / 4.0f + 2.2f);
+    v = v > 0.0f ? v : 0.0f;
+    return v < 4.4f ? v : 4.4f;
+}
+
+// drift coefficient: uniform(-a, a), adcraft/gymnasium_kw_env.py:132-135
+ADC_HD float drift_coeff(uint32_t w, float a) { return fma32(2.0f * a, unit_closed24(w), -a); }
+
+// synthetic action: round2(U(lo, hi))
+ADC_HD float synthetic_bid(uint32_t w, float lo, float hi)
+{
+    const float b = fma32(hi - lo, unit_closed24(w), lo);
+    return __builtin_rintf(b * 100.0f) / 100.0f;
+}
+
+// the 24-way split of a day's volume, adcraft/bidding_simulation.py:151-167
+ADC_HD void cell_range(int32_t V, int t, int32_t &j0, int32_t &n)
+{
+    const int32_t s = V / kTimesteps;
+    const int32_t first = V - (kTimesteps - 1) * s;
+    if (t == 0) { j0 = 0; n = first; }
+    else { j0 = first + (t - 1) * s; n = s; }
+}
+
+}  // namespace adc

@@ -1,0 +1,86 @@
+// adc_shims.cpp - scalar entry points that mirror the reference's pyo3 module `adcraft.rust`
+// function by function (src/lib.rs).  These are the host-side FFI a maintainer binds in place of
+// the Rust crate; the per-step hot path does not go through them (it is adc_engine_step*).
+//
+// The reference's samplers draw from an unseeded thread_rng (src/lib.rs:25,43,61,75,320), so their
+// individual values are not reproducible even by the reference; these take (seed, counter) and
+// draw from the engine's Philox stream with the same float32 transforms the kernels use.
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/adcraft_engine.h"
+#include "adc_law.h"
+
+#define ADC_EXPORT extern "C" __attribute__((visibility("default")))
+
+// src/lib.rs:290-294
+ADC_EXPORT double adc_sigmoid(double x, double s, double t) { return 1.0 / (1.0 + std::exp(-s * (x - t))); }
+
+// src/lib.rs:296-300 (num::clamp)
+ADC_EXPORT double adc_clamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// src/lib.rs:93-105
+ADC_EXPORT double adc_threshold_sigmoid(double p, double impression_thresh, double impression_bid_intercept,
+                                        double impression_slope)
+{
+    const double halver = 2.0 + 1e-10;
+    const double thresh = adc_clamp(halver * impression_thresh, 0.0, 1.0) / halver;
+    const double r = adc_sigmoid(p, impression_slope, impression_bid_intercept);
+    return adc_clamp((1.0 + 2.0 * thresh) * r - thresh, 0.0, 1.0);
+}
+
+// src/lib.rs:108-116,310-312: sequential left-to-right f64 sum
+ADC_EXPORT double adc_sum_f64(const double *x, int64_t n)
+{
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += x[i];
+    return s;
+}
+
+// src/lib.rs:119-127
+ADC_EXPORT int64_t adc_count_true(const uint8_t *x, int64_t n)
+{
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; ++i) c += x[i] != 0;
+    return c;
+}
+
+static inline adc::U4 shim_draw(uint64_t seed, uint64_t counter, uint32_t lane)
+{
+    return adc::philox4x32_10((uint32_t)counter, (uint32_t)(counter >> 32), lane, 0x5348494Du /* "SHIM" */,
+                              (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// src/lib.rs:314-325: round(max(N(mean, std), 0)), f64::round = half away from zero
+ADC_EXPORT uint64_t adc_nonneg_int_normal(double mean, double std, uint64_t seed, uint64_t counter)
+{
+    const adc::U4 w = shim_draw(seed, counter, 0);
+    double x = mean + std * (double)adc::normal_from_word(w.x);
+    if (!(x > 0.0)) x = 0.0;
+    return (uint64_t)std::round(x);
+}
+
+// src/lib.rs:70-76: Binomial(n, p) as n Bernoulli draws
+ADC_EXPORT uint64_t adc_binomial(uint64_t n, double p, uint64_t seed, uint64_t counter)
+{
+    const uint64_t thr = adc::bernoulli_threshold((float)p);
+    uint64_t c = 0;
+    for (uint64_t i = 0; i < n; i += 4) {
+        const adc::U4 w = shim_draw(seed, counter, (uint32_t)(1 + i / 4));
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        for (uint64_t j = 0; j < 4 && i + j < n; ++j) c += adc::bernoulli(ws[j], thr);
+    }
+    return c;
+}
+
+// src/lib.rs:54-67: clamp(sqrt(x)/4 + 4.4/2 + N(0, 1e-10 + sqrt(x)/6), 0, 4.4) - note the constant 4.4
+ADC_EXPORT int adc_cost_create(double x, int64_t n, uint64_t seed, uint64_t counter, double *out)
+{
+    if (n < 0 || (n > 0 && !out) || !(x >= 0.0)) return ADC_EINVAL;
+    for (int64_t i = 0; i < n; i += 4) {
+        const adc::U4 w = shim_draw(seed, counter, (uint32_t)(1 + i / 4));
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        for (int64_t j = 0; j < 4 && i + j < n; ++j) out[i + j] = (double)adc::explicit_cost(ws[j], (float)x);
+    }
+    return ADC_OK;
+}

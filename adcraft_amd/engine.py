@@ -1,0 +1,196 @@
+"""StepEngine: thin object wrapper over the C ABI (include/adcraft_engine.h).
+
+One engine = N environments x K keywords resident on one MI355X.  The per-step hot path of
+the reference (adcraft/gymnasium_kw_env.py:160-269 -> adcraft/bidding_simulation.py:170-234)
+is ONE call here for all environments.  numpy in / numpy out; device-resident variants for
+consumers that keep actions and observations in HBM.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (MODEL_EXPLICIT, MODEL_IMPLICIT, P_A, P_B, P_BCTR, P_COUNT, P_REV_MEAN, P_REV_STD, P_SCTR,  # noqa: F401
+                   P_VOL_MEAN, P_VOL_STD, check, ptr)
+
+_OUT_SPEC = (("impressions", np.int32, True), ("buyside_clicks", np.int32, True),
+             ("sellside_conversions", np.int32, True), ("cost", np.float32, True), ("revenue", np.float32, True),
+             ("reward", np.float64, False), ("cumulative_profit", np.float64, False), ("days_passed", np.int32, False),
+             ("terminated", np.uint8, False), ("truncated", np.uint8, False))
+
+
+class StepEngine:
+    def __init__(self, num_envs, num_keywords, model=MODEL_IMPLICIT, *, device_id=0, max_days=60,
+                 loss_threshold=10000.0, drift=(0.03, 0.03, 0.03), drift_enabled=False, impression_thresh=0.05,
+                 auto_reset=False, env_id_base=0, seed=0):
+        self._h = None
+        self._lib = _ffi.lib()
+        self.num_envs, self.num_keywords, self.model = int(num_envs), int(num_keywords), int(model)
+        cfg = _ffi.Config(C.sizeof(_ffi.Config), int(device_id), self.num_envs, self.num_keywords, self.model,
+                          int(max_days), float(loss_threshold), float(drift[0]), float(drift[1]), float(drift[2]),
+                          1 if drift_enabled else 0, float(impression_thresh), 1 if auto_reset else 0,
+                          int(env_id_base), int(seed) & 0xFFFFFFFFFFFFFFFF)
+        h = C.c_void_p()
+        check(self._lib.adc_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        N, K = self.num_envs, self.num_keywords
+        self.out = {name: np.zeros((N, K) if per_kw else (N,), dtype=dt) for name, dt, per_kw in _OUT_SPEC}
+        self._out = _ffi.StepOut(*(self.out[name].ctypes.data for name, _, _ in _OUT_SPEC))
+
+    # ---- lifecycle
+    def close(self):
+        if self._h is not None:
+            self._lib.adc_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- keyword state
+    def set_params(self, param_id, values):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float32),
+                                                 (self.num_envs, self.num_keywords)))
+        check(self._lib.adc_engine_set_params(self._h, int(param_id), a.ctypes.data))
+
+    def set_all_params(self, planes):
+        """planes: float array [8][N][K] (or broadcastable to it)"""
+        planes = np.asarray(planes, dtype=np.float32)
+        for p in range(P_COUNT):
+            self.set_params(p, planes[p])
+
+    def set_env_params(self, env, planes_8k):
+        a = np.ascontiguousarray(planes_8k, dtype=np.float32).reshape(P_COUNT, self.num_keywords)
+        check(self._lib.adc_engine_set_env_params(self._h, int(env), a.ctypes.data))
+
+    def get_params(self, param_id):
+        a = np.zeros((self.num_envs, self.num_keywords), dtype=np.float32)
+        check(self._lib.adc_engine_get_params(self._h, int(param_id), a.ctypes.data))
+        return a
+
+    def get_all_params(self):
+        return np.stack([self.get_params(p) for p in range(P_COUNT)])
+
+    def reset(self, env_mask=None, seeds=None):
+        m = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8)
+        s = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        if m is not None and m.shape != (self.num_envs,):
+            raise ValueError("env_mask must have shape (num_envs,)")
+        if s is not None and s.shape != (self.num_envs,):
+            raise ValueError("seeds must have shape (num_envs,)")
+        check(self._lib.adc_engine_reset(self._h, ptr(m), ptr(s)))
+
+    def get_rng_state(self):
+        k = np.zeros(self.num_envs, dtype=np.uint64)
+        t = np.zeros(self.num_envs, dtype=np.uint32)
+        check(self._lib.adc_engine_get_rng_state(self._h, k.ctypes.data, t.ctypes.data))
+        return k, t
+
+    def set_rng_state(self, keys=None, ticks=None):
+        k = None if keys is None else np.ascontiguousarray(keys, dtype=np.uint64)
+        t = None if ticks is None else np.ascontiguousarray(ticks, dtype=np.uint32)
+        check(self._lib.adc_engine_set_rng_state(self._h, ptr(k), ptr(t)))
+
+    def get_episode_state(self):
+        d = np.zeros(self.num_envs, dtype=np.int32)
+        c = np.zeros(self.num_envs, dtype=np.float64)
+        check(self._lib.adc_engine_get_episode_state(self._h, d.ctypes.data, c.ctypes.data))
+        return d, c
+
+    def set_episode_state(self, day=None, cum_profit=None):
+        d = None if day is None else np.ascontiguousarray(day, dtype=np.int32)
+        c = None if cum_profit is None else np.ascontiguousarray(cum_profit, dtype=np.float64)
+        check(self._lib.adc_engine_set_episode_state(self._h, ptr(d), ptr(c)))
+
+    # ---- the hot path
+    def _actions(self, bids, budget):
+        b = np.ascontiguousarray(np.broadcast_to(np.asarray(bids, dtype=np.float32), (self.num_envs, self.num_keywords)))
+        g = np.ascontiguousarray(np.broadcast_to(np.asarray(budget, dtype=np.float32), (self.num_envs,)))
+        return b, g
+
+    def step(self, bids, budget, copy=True):
+        """host in / host out, synchronous.  Returns dict of numpy arrays (views of reused buffers if copy=False)."""
+        b, g = self._actions(bids, budget)
+        check(self._lib.adc_engine_step(self._h, b.ctypes.data, g.ctypes.data, C.byref(self._out)))
+        return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+    def step_replay(self, bids, budget, tape, copy=True):
+        b, g = self._actions(bids, budget)
+        check(self._lib.adc_engine_step_replay(self._h, b.ctypes.data, g.ctypes.data, C.byref(tape.struct), C.byref(self._out)))
+        return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+    def step_device(self, d_bids=None, d_budget=None):
+        """asynchronous; None = the engine's staging buffers (see sample_actions / device_buffer)."""
+        check(self._lib.adc_engine_step_device(self._h, d_bids, d_budget))
+
+    def fetch(self, copy=True):
+        check(self._lib.adc_engine_fetch(self._h, C.byref(self._out)))
+        return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+    def synchronize(self):
+        check(self._lib.adc_engine_synchronize(self._h))
+
+    def update_keywords(self):
+        check(self._lib.adc_engine_update_keywords(self._h))
+
+    def sample_actions(self, bid_lo=0.30, bid_hi=1.00, budget=1.0e9):
+        check(self._lib.adc_engine_sample_actions(self._h, bid_lo, bid_hi, budget))
+
+    def device_buffer(self, buffer_id):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        check(self._lib.adc_engine_device_buffer(self._h, int(buffer_id), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stream(self):
+        p = C.c_void_p()
+        check(self._lib.adc_engine_stream(self._h, C.byref(p)))
+        return p.value
+
+    # ---- measurement / metrics
+    def profile_enable(self, on=True):
+        check(self._lib.adc_engine_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        check(self._lib.adc_engine_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def metrics_enable(self, on=True):
+        check(self._lib.adc_engine_metrics_enable(self._h, 1 if on else 0))
+
+    def metrics_reset(self):
+        check(self._lib.adc_engine_metrics_reset(self._h))
+
+    def metrics_read(self):
+        kp = np.zeros(self.num_keywords, dtype=np.int64)
+        sc = np.zeros(8, dtype=np.int64)
+        check(self._lib.adc_engine_metrics_read(self._h, kp.ctypes.data, sc.ctypes.data))
+        return kp, sc
+
+
+class ReplayTape:
+    """Host-side tape for StepEngine.step_replay: the variates the reference drew, in its order."""
+
+    def __init__(self, num_envs, volumes, bid_cents=(), click=(), conv=(), rev_cents=(), x_impressions=(), x_cost=(),
+                 offsets=None):
+        N = int(num_envs)
+        self.vol = np.ascontiguousarray(volumes, dtype=np.int32)
+        self.bid = np.ascontiguousarray(bid_cents, dtype=np.int32)
+        self.click = np.ascontiguousarray(click, dtype=np.uint8)
+        self.conv = np.ascontiguousarray(conv, dtype=np.uint8)
+        self.rev = np.ascontiguousarray(rev_cents, dtype=np.int32)
+        self.ximp = np.ascontiguousarray(x_impressions, dtype=np.int32)
+        self.xcost = np.ascontiguousarray(x_cost, dtype=np.float64)
+        names = ("bid", "ximp", "xcost", "click", "conv", "rev")
+        offsets = offsets or {}
+        self.off = {n: np.ascontiguousarray(offsets.get(n, np.zeros(N)), dtype=np.int64) for n in names}
+        self.end = {n: np.zeros(N, dtype=np.int64) for n in names}
+        self.struct = _ffi.Tape(
+            self.vol.ctypes.data, self.bid.ctypes.data, self.ximp.ctypes.data, self.xcost.ctypes.data,
+            self.click.ctypes.data, self.conv.ctypes.data, self.rev.ctypes.data,
+            self.bid.size, self.ximp.size, self.xcost.size, self.click.size, self.conv.size, self.rev.size,
+            *(self.off[n].ctypes.data for n in names), *(self.end[n].ctypes.data for n in names))

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the BiddingSimulation step engine on N MI355X GPUs of one node.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run, one rank per GPU.  A "step" is one pass of the hot path (one
+BiddingSimulation.step for every resident env) over device-resident synthetic actions.
+Workload at every N: BASELINE.json configs[1] per GPU (4096 envs x 256 keywords, dense stationary
+keyword law) - envs shard with no data-path collective, so scaling is weak; for N>1 the episode
+metric vector is all-reduced over RCCL (torch.distributed "nccl") every max_days steps.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_U = {False: 56, True: 68}   # 36 B read + 20 B written per keyword-step (+12 B drift write-back)
+BYTES_PER_ENV = 26
+
+
+def cpu_baseline(cfg_name, planes, K, seconds=12.0):
+    """the CPU oracle (a C restatement of the reference's loops, oracle/adcraft_oracle.c) on this host's cores,
+    on a bounded sample of the same workload"""
+    from oracle import capi as orc
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    n_envs = 8 * cores
+    o = orc.OracleEngine(n_envs, K, threads=cores)
+    o.params[:] = planes[:, :n_envs]
+    o.key[:] = np.arange(1, n_envs + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    bids = o.sample_bids(0.3, 1.0)
+    o.step(bids, 1.0e9)                      # warm
+    t0 = time.perf_counter()
+    steps = 0
+    auctions = 0
+    while time.perf_counter() - t0 < seconds:
+        out = o.step(bids, 1.0e9)
+        auctions += int(out["volumes"].sum())
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n_envs * K * steps / dt, "unit": "keyword-steps/s", "cores": cores, "kind": "port",
+            "auctions_per_s": auctions / dt,
+            "sample": f"{n_envs} envs x {K} keywords of {cfg_name}, {steps} steps, {dt:.1f} s, OpenMP over envs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", help="cfg2 (metric config), cfg3, cfg4, cfg5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from adcraft_amd import _ffi, synthetic
+    from adcraft_amd.engine import StepEngine
+
+    N, K, mean_volume, cvr, no_vol_prob, drift = synthetic.CONFIGS[args.config]
+    max_days = 60
+    planes = synthetic.implicit_keyword_planes(N, K, seed=1729 + rank, mean_volume=mean_volume, cvr=cvr,
+                                               no_vol_prob=no_vol_prob)
+    eng = StepEngine(N, K, device_id=local_rank, seed=1729, env_id_base=rank * N, max_days=max_days,
+                     loss_threshold=1.0e12, drift_enabled=drift, auto_reset=True)
+    eng.set_all_params(planes)
+    eng.reset()
+    eng.sample_actions(0.30, 1.00, 1.0e9)        # actions resident in HBM before the timed region
+    eng.metrics_enable(True)
+
+    def metric_allreduce():
+        kp, sc = eng.metrics_read()
+        if dist is not None:
+            import torch
+            t = torch.from_numpy(np.concatenate([kp, sc])).cuda()
+            dist.all_reduce(t)                   # the single RCCL collective of the path (episode metric)
+            return t.cpu().numpy()
+        return np.concatenate([kp, sc])
+
+    def barrier():
+        eng.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step_device()
+    barrier()
+    eng.metrics_reset()
+    eng.profile_enable(True)
+    eng.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        eng.step_device()
+        if dist is not None and (s + 1) % max_days == 0:
+            metric_allreduce()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.profile_read()
+    eng.profile_enable(False)
+    totals = metric_allreduce()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        units = float(world) * N * K * args.steps
+        auctions = None
+        b_alg = BYTES_PER_U[drift] * N * K + BYTES_PER_ENV * N            # algorithmic bytes per launch (one GPU)
+        k_ms = kernel_ms / max(launches, 1)
+        achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/sec (envs x keywords auctions/s)",
+            "value": units / elapsed,
+            "unit": "keyword-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32 cents + f32 (Philox4x32-10 u32)", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {N} envs x {K} keywords per GPU, IMPLICIT keywords, "
+                                   f"mean_volume {mean_volume}, cvr {cvr}, no_vol_prob {no_vol_prob}, drift {drift}, "
+                                   f"budget non-binding, {max_days}-step episodes with auto-reset",
+                       "envs_per_gpu": N, "keywords": K, "parallelism": f"env-sharded x{world}"},
+            "env_steps_per_s": float(world) * N * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_step_implicit_fast", "kernel_ms": k_ms, "launches": int(launches),
+                         "algorithmic_bytes_per_launch": b_alg},
+        }
+        sc = totals[K:]
+        line["episode_metric"] = {"profit_dollars": float(sc[0]) / 100.0, "env_steps": int(sc[1]), "episodes": int(sc[2])}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.config, planes, K, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

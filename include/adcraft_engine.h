@@ -1,0 +1,223 @@
+/*
+ * adcraft_engine.h - C ABI of the MI355X-native vectorised BiddingSimulation step engine.
+ *
+ * This is the drop-in boundary for the reference's per-step hot path.  The reference crosses
+ * its native boundary through the pyo3 module `adcraft.rust` (src/lib.rs:14-15,
+ * pyproject.toml:38-40) ~10 times per (sub-timestep, keyword) from
+ * adcraft/bidding_simulation.py:44-234 and adcraft/gymnasium_kw_env.py:160-269.  A replacement
+ * binds ONE call per step for ALL environments instead (adc_engine_step*), plus the scalar
+ * entry points that mirror `adcraft.rust` one-to-one for callers that still want them.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch/Python types.
+ *   - every function returns ADC_OK (0) or a negative adc_status; adc_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - host buffers are caller-allocated and only borrowed for the duration of the call; device
+ *     state is owned by the engine handle; adc_engine_destroy frees it.
+ *   - an engine handle is not thread-safe (one caller at a time, like a gym env); different
+ *     handles are independent.  ctypes releases the GIL during calls.
+ *   - there is NO CPU backend: with no usable HIP device adc_engine_create fails with ADC_EHIP.
+ *
+ * Layout: all per-keyword arrays are [num_envs][num_keywords], keyword fastest (row-major),
+ * parameter planes are [ADC_P_COUNT][num_envs][num_keywords].
+ */
+#ifndef ADCRAFT_ENGINE_H
+#define ADCRAFT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADC_ABI_VERSION 1
+
+typedef enum adc_status {
+    ADC_OK = 0,
+    ADC_EINVAL = -1,   /* bad argument (-> ValueError / AssertionError in the Python host layer) */
+    ADC_EHIP = -2,     /* HIP runtime failure or no device (-> RuntimeError) */
+    ADC_ENOMEM = -3,   /* device or host allocation failed (-> MemoryError) */
+    ADC_ESTATE = -4,   /* call not valid in the current state, e.g. step before reset */
+    ADC_ETYPE = -5     /* wrong element type for a reducer shim (-> TypeError, see adcraft.rust tests) */
+} adc_status;
+
+/* keyword model: which of the reference's two Keyword subclasses the engine simulates */
+typedef enum adc_model {
+    ADC_MODEL_IMPLICIT = 0,  /* ImplicitKeyword: literal 2nd-price auction vs one sampled competitor bid
+                                (adcraft/synthetic_kw_classes.py:578-646, gymnasium_kw_utils.py:169-195) */
+    ADC_MODEL_EXPLICIT = 1   /* ExplicitKeyword: sigmoid impression rate + Binomial + parametric cost
+                                (adcraft/synthetic_kw_classes.py:457-575, gymnasium_kw_utils.py:67-96) */
+} adc_model;
+
+/* parameter planes (float32).  Slots 2,3 depend on the model. */
+typedef enum adc_param {
+    ADC_P_VOL_MEAN = 0,   /* volume ~ round(max(N(mean, std), 0)), src/lib.rs:314-325 */
+    ADC_P_VOL_STD = 1,
+    ADC_P_A = 2,          /* IMPLICIT: competitor-bid Laplace loc   | EXPLICIT: impression_bid_intercept */
+    ADC_P_B = 3,          /* IMPLICIT: competitor-bid Laplace scale | EXPLICIT: impression_slope */
+    ADC_P_BCTR = 4,       /* buyside_ctr */
+    ADC_P_SCTR = 5,       /* sellside_paid_ctr */
+    ADC_P_REV_MEAN = 6,   /* revenue ~ round2(max(N(mean, std), 0.01)), synthetic_kw_helpers.py:66-70 */
+    ADC_P_REV_STD = 7,
+    ADC_P_COUNT = 8
+} adc_param;
+
+typedef struct adc_config {
+    uint32_t struct_size;      /* sizeof(adc_config), for forward compatibility */
+    int32_t device_id;         /* HIP device ordinal */
+    int32_t num_envs;          /* environments resident on this device */
+    int32_t num_keywords;      /* keywords per environment (BiddingSimulation.num_keywords) */
+    int32_t model;             /* adc_model */
+    int32_t max_days;          /* gymnasium_kw_env.py:61,228 */
+    double loss_threshold;     /* dollars; gymnasium_kw_env.py:60,225 */
+    float drift_vol;           /* updater_params [["vol",a],["ctr",b],["cvr",c]], gymnasium_kw_env.py:62 */
+    float drift_ctr;
+    float drift_cvr;
+    int32_t drift_enabled;     /* updater_mask == [True]*K (the only mask the reference's configs use) */
+    float impression_thresh;   /* EXPLICIT: impression_thresh, 0.05 in the env (gymnasium_kw_utils.py:81) */
+    int32_t auto_reset;        /* vector form: a finished env restarts (day=0, cum=0) after reporting */
+    int64_t env_id_base;       /* global id of local env 0 (multi-GPU sharding; used for default keys) */
+    uint64_t seed;             /* engine seed; env e gets key = mix(seed, env_id_base + e) until reset with a seed */
+} adc_config;
+
+/* caller-allocated host outputs of one step; any pointer may be NULL to skip that copy */
+typedef struct adc_step_out {
+    int32_t *impressions;      /* [N*K] obs["impressions"] */
+    int32_t *buyside_clicks;   /* [N*K] obs["buyside_clicks"] */
+    int32_t *sellside_conversions; /* [N*K] */
+    float *cost;               /* [N*K] dollars, obs["cost"] */
+    float *revenue;            /* [N*K] dollars, obs["revenue"] */
+    double *reward;            /* [N]   step profit, gymnasium_kw_env.py:222,230 */
+    double *cumulative_profit; /* [N]   after the step, :223,242 */
+    int32_t *days_passed;      /* [N]   after the step, :227,243 */
+    uint8_t *terminated;       /* [N]   :228 */
+    uint8_t *truncated;        /* [N]   :225 */
+} adc_step_out;
+
+/* device-resident buffers of the engine (for zero-copy consumers: torch / DLPack / RL on GPU) */
+typedef enum adc_buffer {
+    ADC_BUF_PARAMS = 0,        /* float [8][N][K] */
+    ADC_BUF_BIDS = 1,          /* float [N][K]  engine-owned action staging buffer */
+    ADC_BUF_BUDGET = 2,        /* float [N] */
+    ADC_BUF_IMPRESSIONS = 3,   /* int32 [N][K] */
+    ADC_BUF_CLICKS = 4,
+    ADC_BUF_CONVERSIONS = 5,
+    ADC_BUF_COST = 6,          /* float [N][K] */
+    ADC_BUF_REVENUE = 7,
+    ADC_BUF_REWARD = 8,        /* double [N] */
+    ADC_BUF_CUM_PROFIT = 9,    /* double [N] */
+    ADC_BUF_DAYS = 10,         /* int32 [N] */
+    ADC_BUF_TERMINATED = 11,   /* uint8 [N] */
+    ADC_BUF_TRUNCATED = 12,
+    ADC_BUF_METRIC_PROFIT = 13,/* int64 [K]  sum over local envs and steps of keyword profit, cents (IMPLICIT) */
+    ADC_BUF_METRIC_SCALARS = 14,/* int64 [8]  {profit_cents, env_steps, episodes, truncations, auctions, 0,0,0} */
+    ADC_BUF_FLAT_OBS = 15      /* float [N][5K+2] FlatArrayWrapper layout (adcraft/wrappers/flat_array.py:74-80) */
+} adc_buffer;
+
+/* replay ("tape") variate source: the variates the reference drew, in the order it drew them
+ * (t-major, keyword-minor; adcraft/bidding_simulation.py:216-233).  Used for bit-exact parity
+ * against fixtures recorded from the reference.  Per-env start offsets index the flat tapes;
+ * `*_end` (nullable, [N]) receives the cursor after the step. */
+typedef struct adc_tape {
+    const int32_t *volumes;        /* [N*K] auction volume of each keyword this step */
+    const int32_t *bid_cents;      /* IMPLICIT: competitor bids in cents, n per visited cell */
+    const int32_t *x_impressions;  /* EXPLICIT: Binomial result per visited cell */
+    const double *x_cost;          /* EXPLICIT: per-impression costs */
+    const uint8_t *click;          /* one per won auction (IMPLICIT) / per cost entry incl. phantom (EXPLICIT) */
+    const uint8_t *conv;           /* one per paid click */
+    const int32_t *rev_cents;      /* one per conversion */
+    int64_t len_bid, len_ximp, len_xcost, len_click, len_conv, len_rev;  /* tape lengths (bounds checks) */
+    const int64_t *off_bid, *off_ximp, *off_xcost, *off_click, *off_conv, *off_rev;   /* [N] start cursors */
+    int64_t *end_bid, *end_ximp, *end_xcost, *end_click, *end_conv, *end_rev;         /* [N] nullable */
+} adc_tape;
+
+typedef struct adc_engine adc_engine;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+int adc_abi_version(void);
+const char *adc_last_error(void);
+int adc_device_count(int *count);
+int adc_engine_create(const adc_config *cfg, adc_engine **out);
+void adc_engine_destroy(adc_engine *e);
+
+/* ---- keyword state (what reset() generates host-side: gymnasium_kw_env.py:303-316) --------------- */
+/* one parameter plane for all envs, host float [N*K] */
+int adc_engine_set_params(adc_engine *e, int param_id, const float *host_nk);
+int adc_engine_get_params(adc_engine *e, int param_id, float *host_nk);   /* applies pending drift first */
+/* all 8 planes of ONE env, host float [8][K] */
+int adc_engine_set_env_params(adc_engine *e, int env, const float *host_8k);
+
+/* reset(): day=0, cumulative_profit=0 for envs with env_mask[e]!=0 (NULL = all);
+ * seeds (nullable, [N]) re-key the env's random stream (reset(seed=...)); gymnasium_kw_env.py:271-346 */
+int adc_engine_reset(adc_engine *e, const uint8_t *env_mask, const uint64_t *seeds);
+
+/* random-stream state of every env: Philox key [N] and step counter ("tick") [N]; with the episode state
+ * below this is everything needed to checkpoint / resume an engine (the parameters come from get_params) */
+int adc_engine_get_rng_state(adc_engine *e, uint64_t *keys_n, uint32_t *ticks_n);
+int adc_engine_set_rng_state(adc_engine *e, const uint64_t *keys_n, const uint32_t *ticks_n);
+/* episode state: current_day [N], cumulative_profit in dollars [N] (gymnasium_kw_env.py:327-328) */
+int adc_engine_get_episode_state(adc_engine *e, int32_t *day_n, double *cum_profit_n);
+int adc_engine_set_episode_state(adc_engine *e, const int32_t *day_n, const double *cum_profit_n);
+
+/* ---- the hot path: BiddingSimulation.step for all envs (gymnasium_kw_env.py:160-269) ------------- */
+/* host in / host out, synchronous.  bids [N*K] (action["keyword_bids"]), budget [N] (action["budget"]). */
+int adc_engine_step(adc_engine *e, const float *bids_nk, const float *budget_n, adc_step_out *out);
+/* device in / device out, asynchronous on the engine's stream (NULL = use the engine's staging buffers) */
+int adc_engine_step_device(adc_engine *e, const float *d_bids_nk, const float *d_budget_n);
+/* copy the last step's outputs to host buffers (synchronises) */
+int adc_engine_fetch(adc_engine *e, adc_step_out *out);
+int adc_engine_synchronize(adc_engine *e);
+/* replay a recorded tape instead of the engine's own random stream (parity mode) */
+int adc_engine_step_replay(adc_engine *e, const float *bids_nk, const float *budget_n, const adc_tape *tape,
+                           adc_step_out *out);
+/* BiddingSimulation.update_keywords() called directly (gymnasium_kw_env.py:114-158) */
+int adc_engine_update_keywords(adc_engine *e);
+
+/* ---- device-resident access ---------------------------------------------------------------------- */
+int adc_engine_device_buffer(adc_engine *e, int buffer_id, void **dptr, size_t *bytes);
+int adc_engine_stream(adc_engine *e, void **hip_stream);
+/* fill the engine's action staging buffers with synthetic actions: bid = round2(U(lo,hi)) from the
+ * engine's ACTION stream at the current tick, budget = `budget` for every env */
+int adc_engine_sample_actions(adc_engine *e, float bid_lo, float bid_hi, float budget);
+/* FlatArrayWrapper-compatible action [N][K+1] = [budget, bids...] (device pointer) -> staging buffers */
+int adc_engine_set_flat_actions_device(adc_engine *e, const float *d_flat_n_k1);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+/* when enabled, every launch of the dominant step kernel is bracketed by HIP events on the engine stream */
+int adc_engine_profile_enable(adc_engine *e, int enabled);
+/* sum of kernel durations and number of launches since enable/last read; resets the counters */
+int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, int64_t *launches);
+
+/* ---- episode metrics (adcraft/experiment_utils/experiment_metrics.py:64-83) ----------------------- */
+int adc_engine_metrics_enable(adc_engine *e, int enabled);
+int adc_engine_metrics_reset(adc_engine *e);
+/* local (this device) accumulators to host: keyword_profit_cents [K], scalars [8] */
+int adc_engine_metrics_read(adc_engine *e, int64_t *keyword_profit_cents_k, int64_t *scalars8);
+/* ideal (max expected) profit per keyword from the CURRENT parameters, 2048 sampled competitor bids and
+ * the bid grid 0.01..2.99 (experiment_metrics.py:20-61); host double [N*K] */
+int adc_engine_ideal_profit(adc_engine *e, int n_samples, double *host_nk);
+
+/* ---- standalone auction clearing (adcraft/synthetic_kw_helpers.py:116-180) ------------------------ */
+/* other_bids: host double [n_auctions][n_bidders]; placements/costs: host, capacity n_auctions.
+ * Returns the impression count in *impressions.  num_winners + n must be <= 32. */
+int adc_nth_price_auction(int device_id, double bid, const double *other_bids, int32_t n_auctions, int32_t n_bidders,
+                          int32_t n, int32_t num_winners, int32_t *impressions, int32_t *placements, double *costs);
+
+/* ---- scalar entry points mirroring `adcraft.rust` (src/lib.rs, function by function) -------------- */
+double adc_sigmoid(double x, double s, double t);                               /* src/lib.rs:79-83,290-294 */
+double adc_clamp(double x, double lo, double hi);                               /* probify_float, :86-90 */
+double adc_threshold_sigmoid(double p, double impression_thresh,
+                             double impression_bid_intercept, double impression_slope);   /* :93-105 */
+double adc_sum_f64(const double *x, int64_t n);                                 /* sum_array / sum_list, :108-116 */
+int64_t adc_count_true(const uint8_t *x, int64_t n);                            /* sum_array_bool / sum_list_bool */
+/* samplers: the reference draws from an unseeded thread_rng (src/lib.rs:25,61,75,320); these draw from a
+ * Philox stream keyed by (seed, counter) so callers can be reproducible. */
+uint64_t adc_nonneg_int_normal(double mean, double std, uint64_t seed, uint64_t counter);   /* :314-325 */
+uint64_t adc_binomial(uint64_t n, double p, uint64_t seed, uint64_t counter);               /* :70-76 */
+int adc_cost_create(double x, int64_t n, uint64_t seed, uint64_t counter, double *out_n);   /* :54-67 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADCRAFT_ENGINE_H */

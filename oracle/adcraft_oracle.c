@@ -1,0 +1,578 @@
+/*
+ * adcraft_oracle.c - CPU ORACLE for the BiddingSimulation step path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (adcraft_amd/) never links,
+ * imports or calls anything in this directory and has no CPU fallback.
+ *
+ * It restates, in plain C, the reference's per-step algorithm literally - the same loops
+ * in the same order - and cites the reference lines each function follows:
+ *
+ *   orc_nth_price_auction        adcraft/synthetic_kw_helpers.py:116-180
+ *   cell walk (campaign loop)    adcraft/bidding_simulation.py:170-234
+ *   one (t,k) cell               adcraft/bidding_simulation.py:44-120
+ *   24-way volume split          adcraft/bidding_simulation.py:151-167
+ *   step tail                    adcraft/gymnasium_kw_env.py:197-244
+ *   drift                        adcraft/gymnasium_kw_env.py:114-158
+ *   EXPLICIT cell (+phantom)     adcraft/synthetic_kw_classes.py:493-538, src/lib.rs:54-76,93-105
+ *   volume                       src/lib.rs:314-325
+ *
+ * Two variate sources:
+ *   TAPE   - the variates are supplied by the caller in the order the reference draws them
+ *            (competitor bids, click booleans, conversion booleans, revenues ...).  Pinned
+ *            bit-exactly against tests/golden/g3_*.json and g8_*.json, which were recorded
+ *            from the reference itself (tools/gen_golden.py).
+ *   PHILOX - the production stream: Philox4x32-10 addressed by (env key; auction index, stage,
+ *            keyword, tick), with float32 transforms built only from IEEE-exact operations
+ *            (+ - * / sqrt fma rint), so a GPU computes bit-identical values.  The Philox core is
+ *            pinned by the Random123 known-answer vectors, the transforms by closed forms
+ *            (tests/test_oracle_*.py).
+ *
+ * Parity status: pinned (TAPE mode against reference-generated fixtures).  The reference's
+ * own step-time random stream (numpy PCG64 interleaved with unseeded Rust thread_rng,
+ * src/lib.rs:25,43,61,75,320) is not reproducible even by the reference; PHILOX mode is
+ * this project's stream and is checked distributionally against the reference's laws.
+ *
+ * Money: IMPLICIT bids, competitor bids and revenues are whole cents in the reference
+ * (gymnasium_kw_env.py:215, synthetic_kw_helpers.py:68-70,108-113), so the oracle carries
+ * integer cents.  EXPLICIT costs are un-rounded reals (src/lib.rs:60-64) and are carried as
+ * doubles in the reference's own operation order.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1 };
+enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT };
+/* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
+enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6 };
+#define ORC_TIMESTEPS 24
+#define ORC_VMAX (1 << 20)
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC11); constants of Random123. */
+ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void draw(uint64_t key, uint32_t index, uint32_t stage, uint32_t kw, uint32_t tick, uint32_t w[4])
+{
+    uint32_t c[4] = { index, stage, kw, tick };
+    uint32_t k[2] = { (uint32_t)key, (uint32_t)(key >> 32) };
+    orc_philox4x32_10(c, k, w);
+}
+
+/* ------------------------------------------------------------------ deterministic f32 math */
+/* Every step is one correctly-rounded IEEE operation, written out explicitly (no contraction:
+ * build with -ffp-contract=off), so any conforming CPU or GPU produces the same bits. */
+static float as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* natural log of a positive normal float; Cephes logf scheme */
+ORC_API float orc_det_logf(float x)
+{
+    static const float P[9] = { 7.0376836292E-2f, -1.1514610310E-1f, 1.1676998740E-1f, -1.2420140846E-1f,
+                                1.4249322787E-1f, -1.6668057665E-1f, 2.0000714765E-1f, -2.4999993993E-1f,
+                                3.3333331174E-1f };
+    uint32_t u = as_u32(x);
+    int e = (int)(u >> 23) - 126;                          /* x = m * 2^e, m in [0.5,1) */
+    float m = as_f32((u & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = P[0];
+    for (int i = 1; i < 9; ++i) p = fmaf(p, f, P[i]);
+    float y = f * (z * p);
+    float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    float r = f + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+/* e^x for |x| <= 87; Cephes expf scheme */
+ORC_API float orc_det_expf(float x)
+{
+    if (x > 87.0f) x = 87.0f;
+    if (x < -87.0f) x = -87.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float z = r * r;
+    float p = 1.9875691500E-4f;
+    p = fmaf(p, r, 1.3981999507E-3f);
+    p = fmaf(p, r, 8.3334519073E-3f);
+    p = fmaf(p, r, 4.1665795894E-2f);
+    p = fmaf(p, r, 1.6666665459E-1f);
+    p = fmaf(p, r, 5.0000001201E-1f);
+    float y = fmaf(p, z, r) + 1.0f;
+    int ni = (int)n;
+    return y * as_f32((uint32_t)(ni + 127) << 23);
+}
+
+/* uniform strictly inside (0,1) from the top 23 bits: (i + 1/2) / 2^23, exact in f32 */
+static float u23(uint32_t w) { return ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+/* uniform in [0,1) from the top 24 bits */
+static float u24(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
+/* standard normal from one word: sign bit 8, lower-tail probability from bits 31..9;
+ * Wichura's AS241 PPND7 rational approximations (Appl. Statist. 37 (1988) 477-484). */
+ORC_API float orc_normal_from_word(uint32_t w)
+{
+    float p = ((float)(w >> 9) + 0.5f) * 5.9604644775390625e-08f;   /* (0, 0.5) */
+    float q = p - 0.5f;
+    float val;
+    if (q >= -0.425f) {
+        float r = fmaf(-q, q, 0.180625f);
+        float num = fmaf(fmaf(fmaf(5.9109374720e1f, r, 1.5929113202e2f), r, 5.0434271938e1f), r, 3.3871327179e0f);
+        float den = fmaf(fmaf(fmaf(6.7187563600e1f, r, 7.8757757664e1f), r, 1.7895169469e1f), r, 1.0f);
+        val = q * num / den;                                          /* <= 0 */
+    } else {
+        float r = sqrtf(-orc_det_logf(p)) - 1.6f;
+        float num = fmaf(fmaf(fmaf(1.7023821103e-1f, r, 1.3067284816e0f), r, 2.7568153900e0f), r, 1.4234372777e0f);
+        float den = fmaf(fmaf(1.2021132975e-1f, r, 7.3700164250e-1f), r, 1.0f);
+        val = -(num / den);
+    }
+    return ((w >> 8) & 1u) ? -val : val;
+}
+
+/* competitor bid in cents: round2(max(|Laplace(loc, scale)|, 0))  (synthetic_kw_helpers.py:104-113)
+ * Laplace(0,1) = random sign x Exponential(1). */
+ORC_API int32_t orc_laplace_cents_from_word(uint32_t w, float loc, float scale)
+{
+    float e = -orc_det_logf(u23(w));
+    float z = ((w >> 8) & 1u) ? e : -e;
+    float a = fabsf(fmaf(scale, z, loc));
+    float c = rintf(a * 100.0f);
+    if (!(c < 1.0e9f)) c = 1.0e9f;
+    return (int32_t)c;
+}
+
+/* Bernoulli threshold: event <=> (uint64)word < T, T = round(p * 2^32) in [0, 2^32]
+ * (reference: rng.random(n) <= p, synthetic_kw_helpers.py:73-77) */
+ORC_API uint64_t orc_bernoulli_threshold(float p)
+{
+    double t = floor((double)p * 4294967296.0 + 0.5);
+    if (!(t > 0.0)) return 0;
+    if (t > 4294967296.0) t = 4294967296.0;
+    return (uint64_t)t;
+}
+
+/* revenue in cents: round2(max(N(mu, sd), 0.01))  (synthetic_kw_helpers.py:66-70) */
+ORC_API int32_t orc_revenue_cents_from_word(uint32_t w, float mu, float sd)
+{
+    float x = fmaf(sd, orc_normal_from_word(w), mu);
+    x = fmaxf(x, 0.01f);
+    float c = rintf(x * 100.0f);
+    if (!(c < 1.0e9f)) c = 1.0e9f;
+    return (int32_t)c;
+}
+
+/* volume: round_half_away(max(N(mean, sd), 0))  (src/lib.rs:314-325) */
+ORC_API int32_t orc_volume_from_word(uint32_t w, float mean, float sd)
+{
+    float x = fmaf(sd, orc_normal_from_word(w), mean);
+    x = fmaxf(x, 0.0f);
+    if (!(x < (float)ORC_VMAX)) x = (float)ORC_VMAX;
+    float t = truncf(x);
+    int32_t v = (int32_t)t + ((x - t) >= 0.5f ? 1 : 0);
+    return v;
+}
+
+/* bid / budget canonicalisation (gymnasium_kw_env.py:199,215): numpy round(x,2) = rint(x*100)/100 in f64 */
+ORC_API int64_t orc_bid_cents(float bid)
+{
+    double c = rint((double)bid * 100.0);
+    if (!(c >= 1.0)) c = 1.0;
+    if (c > 1.0e9) c = 1.0e9;
+    return (int64_t)c;
+}
+ORC_API int64_t orc_budget_cents(float budget)
+{
+    double c = rint((double)budget * 100.0);
+    if (!(c > -9.0e15)) c = -9.0e15;
+    if (c > 9.0e15) c = 9.0e15;
+    return (int64_t)c;
+}
+
+/* EXPLICIT impression probability (src/lib.rs:93-105, 290-300), float32 form used on the step path */
+ORC_API float orc_threshold_sigmoid_f32(float bid, float thresh, float intercept, float slope)
+{
+    float th = 2.0f * thresh;            /* halver = 2 + 1e-10 == 2.0f in float32 */
+    th = fminf(fmaxf(th, 0.0f), 1.0f) / 2.0f;
+    float r = 1.0f / (1.0f + orc_det_expf(-slope * (bid - intercept)));
+    float v = fmaf(fmaf(2.0f, th, 1.0f), r, -th);
+    return fminf(fmaxf(v, 0.0f), 1.0f);
+}
+/* the same in f64 exactly as the Rust source computes it (scalar FFI shim parity) */
+ORC_API double orc_threshold_sigmoid_f64(double p, double thresh, double intercept, double slope)
+{
+    double halver = 2.0 + 1e-10;
+    double t = halver * thresh;
+    t = (t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t)) / halver;
+    double r = 1.0 / (1.0 + exp(-slope * (p - intercept)));
+    double v = (1.0 + 2.0 * t) * r - t;
+    return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+}
+ORC_API double orc_sigmoid_f64(double x, double s, double t) { return 1.0 / (1.0 + exp(-s * (x - t))); }
+
+/* EXPLICIT per-impression cost (src/lib.rs:54-67): clamp(sqrt(x)/4 + 4.4/2 + N(0, 1e-10 + sqrt(x)/6), 0, 4.4) */
+ORC_API float orc_explicit_cost_from_word(uint32_t w, float bid)
+{
+    float sq = sqrtf(bid);
+    float sd = 1e-10f + sq / 6.0f;
+    float v = fmaf(sd, orc_normal_from_word(w), sq / 4.0f + 2.2f);
+    return fminf(fmaxf(v, 0.0f), 4.4f);
+}
+
+/* ------------------------------------------------------------------ nth_price_auction */
+/* synthetic_kw_helpers.py:116-180.  other_bids is [n_auctions][n_bidders] row-major.
+ * Returns impressions; fills placements/costs (length = impressions). */
+static int cmp_f64(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+ORC_API int32_t orc_nth_price_auction(double bid, const double *other_bids, int32_t n_auctions, int32_t n_bidders,
+                                      int32_t n, int32_t num_winners, int32_t *placements, double *costs)
+{
+    int32_t top = num_winners + n, impressions = 0;
+    int32_t width = n_bidders > top ? n_bidders : top;
+    double *row = (double *)malloc(sizeof(double) * (size_t)(width > 0 ? width : 1));
+    for (int32_t a = 0; a < n_auctions; ++a) {
+        const double *src = other_bids + (size_t)a * n_bidders;
+        const double *top_n;
+        if (n_bidders >= top) {                  /* :152-155 top (w+n) bids, ascending */
+            memcpy(row, src, sizeof(double) * n_bidders);
+            qsort(row, n_bidders, sizeof(double), cmp_f64);
+            top_n = row + (n_bidders - top);
+        } else {                                 /* :156-161 pad with zero bids, then sort */
+            for (int32_t i = 0; i < top - n_bidders; ++i) row[i] = 0.0;
+            memcpy(row + (top - n_bidders), src, sizeof(double) * n_bidders);
+            qsort(row, top, sizeof(double), cmp_f64);
+            top_n = row;
+        }
+        int32_t index = 0;                       /* :167 searchsorted(auction, bid), side="left" */
+        while (index < top && top_n[index] < bid) ++index;
+        if (index > n) {                         /* :170 */
+            placements[impressions] = top - index;
+            if (n > 1) {
+                int32_t ci = index - (n - 1);
+                if (ci < 0) ci = 0;
+                costs[impressions] = top_n[ci];
+            } else {
+                costs[impressions] = bid;
+            }
+            ++impressions;
+        }
+    }
+    free(row);
+    return impressions;
+}
+
+/* ------------------------------------------------------------------ the step */
+typedef struct {
+    int32_t num_envs, num_keywords, model, max_days;
+    double loss_threshold;
+    float drift_vol, drift_ctr, drift_cvr;
+    int32_t drift_on;        /* updater_mask all-True */
+    float imp_thresh;        /* EXPLICIT impression_thresh (0.05 in the env, gymnasium_kw_utils.py:81) */
+    int32_t auto_reset;      /* vector form: done envs restart (day=0, cum=0) after reporting */
+    int32_t threads;         /* OpenMP threads over envs (cpu_baseline); 0/1 = serial */
+} orc_config;
+
+typedef struct {             /* TAPE source: flat per-call tapes + cursors (advanced by the step) */
+    const int32_t *volumes;      /* [N][K] */
+    const int32_t *bid_cents;    /* IMPLICIT: competitor bids, n per visited cell */
+    const int32_t *x_impressions;/* EXPLICIT: Binomial result per visited cell */
+    const double *x_cost;        /* EXPLICIT: per-impression costs */
+    const uint8_t *click, *conv;
+    const int32_t *rev_cents;
+    int64_t cur_bid, cur_ximp, cur_xcost, cur_click, cur_conv, cur_rev;  /* in/out */
+} orc_tape;
+
+typedef struct {
+    int32_t *impressions, *clicks, *conversions;   /* [N][K] */
+    int64_t *cost_cents, *revenue_cents;           /* [N][K] IMPLICIT exact money; EXPLICIT revenue only */
+    double *cost, *revenue;                        /* [N][K] dollars (IMPLICIT: cents/100) */
+    int32_t *volumes;                              /* [N][K] V drawn this step */
+    double *reward, *cum_profit;                   /* [N] */
+    int32_t *day;                                  /* [N] days_passed after the step */
+    uint8_t *terminated, *truncated;               /* [N] */
+} orc_out;
+
+typedef struct {             /* persistent per-env state, caller-owned */
+    float *params;           /* [P_COUNT][N][K] */
+    uint64_t *key;           /* [N] */
+    uint32_t *tick;          /* [N] */
+    int32_t *day;            /* [N] */
+    int64_t *cum_cents;      /* [N] IMPLICIT */
+    double *cum;             /* [N] EXPLICIT */
+    uint8_t *drift_pending;  /* [N] */
+} orc_state;
+
+static float P(const orc_state *s, const orc_config *c, int p, int env, int k)
+{
+    return s->params[((size_t)p * c->num_envs + env) * c->num_keywords + k];
+}
+static float *Pp(orc_state *s, const orc_config *c, int p, int env, int k)
+{
+    return &s->params[((size_t)p * c->num_envs + env) * c->num_keywords + k];
+}
+
+/* drift of one env's keywords (gymnasium_kw_env.py:132-158), applied lazily at the start of the
+ * next step: values used by step t+1 equal the reference's values after step t's update. */
+static void apply_drift(const orc_config *c, orc_state *s, int env, uint32_t tick_of_draw)
+{
+    for (int k = 0; k < c->num_keywords; ++k) {
+        uint32_t w[4];
+        draw(s->key[env], 0, ST_DRIFT, (uint32_t)k, tick_of_draw, w);
+        float uv = fmaf(2.0f * c->drift_vol, u24(w[0]), -c->drift_vol);
+        float uc = fmaf(2.0f * c->drift_ctr, u24(w[1]), -c->drift_ctr);
+        float us = fmaf(2.0f * c->drift_cvr, u24(w[2]), -c->drift_cvr);
+        float *vm = Pp(s, c, P_VOL_MEAN, env, k), *bc = Pp(s, c, P_BCTR, env, k), *sc = Pp(s, c, P_SCTR, env, k);
+        float sd0 = P(s, c, P_VOL_STD, env, k);      /* :136-137 "init volume" is the vol std */
+        *vm = fmaxf(fmaf(uv, sd0, *vm), 0.0f);       /* :146-149 */
+        *bc = fminf(fmaxf(*bc * (1.0f + uc), 0.0f), 1.0f);   /* :153-155 */
+        *sc = fminf(fmaxf(*sc * (1.0f + us), 0.0f), 1.0f);   /* :156-158 */
+    }
+}
+
+static void step_env(const orc_config *c, orc_state *s, int env, const float *bids, float budget_in,
+                     orc_tape *tape, orc_out *o)
+{
+    const int K = c->num_keywords;
+    const size_t base = (size_t)env * K;
+    const uint64_t key = s->key[env];
+    const uint32_t tick = s->tick[env];
+    const int use_tape = tape != NULL;
+
+    if (!use_tape && c->drift_on && s->drift_pending[env]) {
+        apply_drift(c, s, env, tick - 1u);
+        s->drift_pending[env] = 0;
+    }
+
+    /* volumes and the 24-way split (bidding_simulation.py:151-167) */
+    int32_t *V = o->volumes + base;
+    for (int k = 0; k < K; ++k) {
+        if (use_tape) V[k] = tape->volumes[base + k];
+        else {
+            uint32_t w[4];
+            draw(key, 0, ST_VOL, (uint32_t)k, tick, w);
+            V[k] = orc_volume_from_word(w[0], P(s, c, P_VOL_MEAN, env, k), P(s, c, P_VOL_STD, env, k));
+        }
+        o->impressions[base + k] = o->clicks[base + k] = o->conversions[base + k] = 0;
+        o->cost_cents[base + k] = o->revenue_cents[base + k] = 0;
+        o->cost[base + k] = o->revenue[base + k] = 0.0;
+    }
+
+    const int64_t budget_cents = orc_budget_cents(budget_in);
+    int64_t remaining_c = budget_cents;                       /* IMPLICIT */
+    double remaining_d = (double)budget_cents / 100.0;        /* EXPLICIT: np.round(budget, 2) */
+    double *profit_k = (double *)calloc((size_t)K, sizeof(double));   /* EXPLICIT per-keyword profit */
+    int stop = 0;
+
+    for (int t = 0; t < ORC_TIMESTEPS && !stop; ++t) {
+        for (int k = 0; k < K && !stop; ++k) {
+            const int32_t stepv = V[k] / ORC_TIMESTEPS;
+            const int32_t n = t == 0 ? V[k] - (ORC_TIMESTEPS - 1) * stepv : stepv;
+            const int32_t j0 = t == 0 ? 0 : V[k] - (ORC_TIMESTEPS - 1) * stepv + (t - 1) * stepv;
+            const int64_t bid_c = orc_bid_cents(bids[base + k]);
+            const uint64_t t_click = orc_bernoulli_threshold(P(s, c, P_BCTR, env, k));
+            const uint64_t t_conv = orc_bernoulli_threshold(P(s, c, P_SCTR, env, k));
+            const float rev_mu = P(s, c, P_REV_MEAN, env, k), rev_sd = P(s, c, P_REV_STD, env, k);
+
+            if (c->model == ORC_IMPLICIT) {
+                /* simulate_epoch_of_bidding, bidding_simulation.py:86-117, in cents */
+                const float loc = P(s, c, P_A, env, k), scale = P(s, c, P_B, env, k);
+                int64_t budget = remaining_c, cell_cost = 0;
+                int32_t wins = 0, paid = 0, convs = 0;
+                int broke = 0;
+                /* pass 1: the auctions (impressions are not budget-limited, :86-88) */
+                int64_t click_cur = tape ? tape->cur_click : 0;
+                for (int32_t i = 0; i < n; ++i) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    int64_t comp;
+                    if (use_tape) comp = tape->bid_cents[tape->cur_bid++];
+                    else {
+                        draw(key, (uint32_t)(j0 + i), ST_AUCTION, (uint32_t)k, tick, w);
+                        comp = orc_laplace_cents_from_word(w[0], loc, scale);
+                    }
+                    if (!(bid_c > comp)) continue;             /* tie loses, helpers.py:167-170 */
+                    ++wins;
+                    int clicked = use_tape ? tape->click[click_cur + wins - 1] : ((uint64_t)w[1] < t_click);
+                    if (!clicked || broke) continue;
+                    if (budget >= comp) {                      /* :97-104 */
+                        budget -= comp; cell_cost += comp; ++paid;
+                        int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w[2] < t_conv);
+                        if (conv) {
+                            int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
+                                                   : orc_revenue_cents_from_word(w[3], rev_mu, rev_sd);
+                            ++convs;
+                            o->revenue_cents[base + k] += rev;
+                        }
+                    } else broke = 1;                          /* break: no later click of this cell is paid */
+                }
+                if (use_tape) tape->cur_click += wins;
+                o->impressions[base + k] += wins;
+                o->clicks[base + k] += paid;
+                o->conversions[base + k] += convs;
+                o->cost_cents[base + k] += cell_cost;
+                remaining_c -= cell_cost;                       /* bidding_simulation.py:225 */
+                if (remaining_c <= 0) stop = 1;                 /* :230-233 */
+            } else {
+                /* EXPLICIT cell: synthetic_kw_classes.py:535-538,514-518 then bidding_simulation.py:94-117 */
+                const float bid_d = (float)((double)bid_c / 100.0);
+                const float p_imp = orc_threshold_sigmoid_f32(bid_d, c->imp_thresh, P(s, c, P_A, env, k), P(s, c, P_B, env, k));
+                const uint64_t t_imp = orc_bernoulli_threshold(p_imp);
+                double budget = remaining_d, cell_cost_sum = 0.0, cell_rev = 0.0;
+                int32_t imps = 0, paid = 0, convs = 0;
+                int broke = 0;
+                int32_t n_imp_tape = use_tape ? tape->x_impressions[tape->cur_ximp++] : -1;
+                int32_t loop_n = use_tape ? n_imp_tape : n;
+                for (int32_t i = 0; i < loop_n; ++i) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    double cost;
+                    if (use_tape) cost = tape->x_cost[tape->cur_xcost++];
+                    else {
+                        draw(key, (uint32_t)(j0 + i), ST_AUCTION, (uint32_t)k, tick, w);
+                        if (!((uint64_t)w[0] < t_imp)) continue;          /* Binomial(n,p) as n Bernoullis, src/lib.rs:70-76 */
+                        cost = (double)orc_explicit_cost_from_word(w[1], bid_d);
+                    }
+                    ++imps;
+                    int clicked = use_tape ? tape->click[tape->cur_click++] : ((uint64_t)w[2] < t_click);
+                    if (!clicked || broke) continue;
+                    if (budget >= cost) {
+                        budget -= cost; cell_cost_sum += cost; ++paid;
+                        o->cost[base + k] += cost;             /* obs cost = sum_list(costs): left-to-right */
+                        int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w[3] < t_conv);
+                        if (conv) {
+                            int64_t rev;
+                            if (use_tape) rev = tape->rev_cents[tape->cur_rev++];
+                            else {
+                                uint32_t w2[4];
+                                draw(key, (uint32_t)(j0 + i), ST_XREV, (uint32_t)k, tick, w2);
+                                rev = orc_revenue_cents_from_word(w2[0], rev_mu, rev_sd);
+                            }
+                            ++convs;
+                            o->revenue_cents[base + k] += rev;
+                            cell_rev += (double)rev / 100.0;
+                        }
+                    } else broke = 1;
+                }
+                if (imps == 0) {
+                    /* phantom: costs = np.array([0]) when impressions < 1 (synthetic_kw_classes.py:514-515),
+                     * one zero-cost click opportunity per sub-timestep */
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    if (!use_tape) draw(key, (uint32_t)t, ST_XPHANTOM, (uint32_t)k, tick, w);
+                    int clicked = use_tape ? tape->click[tape->cur_click++] : ((uint64_t)w[0] < t_click);
+                    if (clicked && budget >= 0.0) {
+                        ++paid;
+                        int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w[1] < t_conv);
+                        if (conv) {
+                            int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
+                                                   : orc_revenue_cents_from_word(w[2], rev_mu, rev_sd);
+                            ++convs;
+                            o->revenue_cents[base + k] += rev;
+                            cell_rev += (double)rev / 100.0;
+                        }
+                    }
+                }
+                o->impressions[base + k] += imps;
+                o->clicks[base + k] += paid;
+                o->conversions[base + k] += convs;
+                profit_k[k] += cell_rev - cell_cost_sum;        /* combine_outcomes: profit += profit */
+                remaining_d -= cell_cost_sum;
+                if (remaining_d <= 0.0) stop = 1;
+            }
+        }
+    }
+
+    /* step tail, gymnasium_kw_env.py:222-244 */
+    double reward;
+    if (c->model == ORC_IMPLICIT) {
+        int64_t profit_c = 0;
+        for (int k = 0; k < K; ++k) {
+            profit_c += o->revenue_cents[base + k] - o->cost_cents[base + k];
+            o->cost[base + k] = (double)o->cost_cents[base + k] / 100.0;
+            o->revenue[base + k] = (double)o->revenue_cents[base + k] / 100.0;
+        }
+        s->cum_cents[env] += profit_c;
+        reward = (double)profit_c / 100.0;
+        o->cum_profit[env] = (double)s->cum_cents[env] / 100.0;
+    } else {
+        reward = 0.0;
+        for (int k = 0; k < K; ++k) {
+            reward += profit_k[k];                              /* rust.sum_list, left to right */
+            o->revenue[base + k] = (double)o->revenue_cents[base + k] / 100.0;
+        }
+        s->cum[env] += reward;
+        o->cum_profit[env] = s->cum[env];
+    }
+    free(profit_k);
+    o->reward[env] = reward;
+    o->truncated[env] = o->cum_profit[env] < -c->loss_threshold;    /* :225 */
+    s->day[env] += 1;                                               /* :227 */
+    o->day[env] = s->day[env];
+    o->terminated[env] = s->day[env] >= c->max_days;                /* :228 */
+    s->tick[env] = tick + 1u;
+    if (c->drift_on) s->drift_pending[env] = 1;                     /* :246 update_keywords() */
+    if (c->auto_reset && (o->terminated[env] || o->truncated[env])) {
+        s->day[env] = 0; s->cum_cents[env] = 0; s->cum[env] = 0.0;  /* :327-328 */
+    }
+}
+
+/* bids [N][K], budget [N]; tape (nullable) serves env 0..N-1 in order (cursors carry over). */
+ORC_API int32_t orc_step(const orc_config *c, orc_state *s, const float *bids, const float *budget,
+                         orc_tape *tape, orc_out *o)
+{
+    if (!c || !s || !bids || !budget || !o) return -1;
+    if (c->num_envs <= 0 || c->num_keywords <= 0) return -1;
+    if (tape || c->threads <= 1) {
+        for (int e = 0; e < c->num_envs; ++e)
+            step_env(c, s, e, bids, budget[e], tape, o);
+    } else {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(c->threads)
+        for (int e = 0; e < c->num_envs; ++e)
+            step_env(c, s, e, bids, budget[e], NULL, o);
+    }
+    return 0;
+}
+
+/* force the pending drift into the stored parameters (what keyword_params shows after a step) */
+ORC_API int32_t orc_materialize_drift(const orc_config *c, orc_state *s)
+{
+    for (int e = 0; e < c->num_envs; ++e)
+        if (c->drift_on && s->drift_pending[e]) { apply_drift(c, s, e, s->tick[e] - 1u); s->drift_pending[e] = 0; }
+    return 0;
+}
+
+/* synthetic action stream used by bench.py and the parity tests: bid = round2(U(lo, hi)) */
+ORC_API void orc_sample_bids(const orc_config *c, const uint64_t *key, const uint32_t *tick, float lo, float hi, float *bids)
+{
+    for (int e = 0; e < c->num_envs; ++e)
+        for (int k = 0; k < c->num_keywords; ++k) {
+            uint32_t w[4];
+            draw(key[e], 0, ST_ACTION, (uint32_t)k, tick[e], w);
+            float b = fmaf(hi - lo, u24(w[0]), lo);
+            bids[(size_t)e * c->num_keywords + k] = rintf(b * 100.0f) / 100.0f;
+        }
+}
+
+ORC_API int32_t orc_abi_version(void) { return 1; }

@@ -1,0 +1,299 @@
+"""-m gpu: the HIP engine (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Bit-exact for every integer (impressions, clicks, conversions, days, flags) and for money
+(integer cents on both sides; the float32 dollars the kernels store are compared against the
+identically rounded oracle cents; f64 reward / cumulative profit compared bitwise).
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import adcraft_amd.engine as eng
+    from adcraft_amd import _ffi
+    assert _ffi.device_count() >= 1, "no HIP device visible: the engine has no CPU path"
+    return eng
+
+
+def _run_vs_oracle(amd, N, K, planes, steps, budget, seed=7, model=0, drift=False, max_days=60, loss_threshold=1e4,
+                   auto_reset=False, bid_lo=0.3, bid_hi=1.0, check_params=False):
+    e = amd.StepEngine(N, K, model=model, seed=seed, drift_enabled=drift, max_days=max_days,
+                       loss_threshold=loss_threshold, auto_reset=auto_reset)
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes, drift_on=drift, max_days=max_days, loss_threshold=loss_threshold,
+                        auto_reset=auto_reset)
+    n_rerun = 0
+    for s in range(steps):
+        bids = o.sample_bids(bid_lo, bid_hi)
+        got = e.step(bids, budget)
+        ref = o.step(bids, budget)
+        H.assert_step_equal(got, ref, implicit=(model == 0))
+        n_rerun += int((ref["cost_cents"].sum(axis=1) >= np.rint(np.float64(np.float32(budget)) * 100)).sum())
+    if check_params:
+        o.materialize_drift()
+        assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+    return n_rerun
+
+
+# ------------------------------------------------------------------ PHILOX mode, fast pass
+@pytest.mark.parametrize("N,K", [(8, 64), (3, 300), (2, 256), (5, 1), (1, 1024), (4, 257)])
+def test_fast_pass_matches_oracle(amd, N, K):
+    planes = H.implicit_params(N, K, seed=N * 1000 + K)
+    _run_vs_oracle(amd, N, K, planes, steps=3, budget=1.0e9)
+
+
+def test_sparse_volume_keywords(amd):
+    """cfg3 law: half the keywords have (0, U*0.5) volume (gymnasium_kw_utils.py:295-300)"""
+    planes = H.implicit_params(6, 320, seed=3, mean_volume=16, cvr=0.1, no_vol_prob=0.5)
+    _run_vs_oracle(amd, 6, 320, planes, steps=4, budget=1.0e9)
+
+
+def test_all_zero_volume_and_extreme_rates(amd):
+    planes = H.implicit_params(2, 70, seed=4)
+    planes[0] = 0.0
+    planes[1] = 0.0
+    _run_vs_oracle(amd, 2, 70, planes, steps=2, budget=1.0e9)
+    planes = H.implicit_params(2, 70, seed=5)
+    planes[4, 0] = 1.0      # ctr 1: every impression is clicked
+    planes[5, 0] = 0.0      # cvr 0: never converts
+    planes[4, 1] = 0.0
+    e = amd.StepEngine(2, 70, seed=1)
+    e.set_all_params(planes)
+    e.reset()
+    out = e.step(np.full((2, 70), 0.9, np.float32), 1e9)
+    assert np.array_equal(out["buyside_clicks"][0], out["impressions"][0]) and out["impressions"][0].sum() > 0
+    assert out["sellside_conversions"][0].sum() == 0 and out["buyside_clicks"][1].sum() == 0
+    e.close()
+    _run_vs_oracle(amd, 2, 70, planes, steps=2, budget=1.0e9)
+
+
+def test_large_volume(amd):
+    planes = H.implicit_params(2, 40, seed=6, mean_volume=3000)
+    _run_vs_oracle(amd, 2, 40, planes, steps=2, budget=1.0e9)
+
+
+# ------------------------------------------------------------------ PHILOX mode, budget binding -> exact pass
+@pytest.mark.parametrize("budget", [300.0, 25.0, 0.5, 0.01])
+def test_binding_budget_matches_oracle(amd, budget):
+    N, K = 6, 48
+    planes = H.implicit_params(N, K, seed=11)
+    n = _run_vs_oracle(amd, N, K, planes, steps=3, budget=budget, bid_lo=0.5, bid_hi=1.2)
+    assert n > 0          # the exact pass really ran
+
+
+def test_mixed_binding_and_not(amd):
+    """some envs hit the budget, others do not, in the same launch"""
+    N, K = 8, 64
+    planes = H.implicit_params(N, K, seed=12)
+    planes[0, ::2] = 8.0          # low-volume envs never reach the budget
+    planes[1, ::2] = 1.0
+    n = _run_vs_oracle(amd, N, K, planes, steps=3, budget=60.0)
+    assert 0 < n < 3 * N
+
+
+def test_episode_tail_termination_truncation_autoreset(amd):
+    N, K = 4, 32
+    planes = H.implicit_params(N, K, seed=13, cvr=0.1)       # loses money
+    _run_vs_oracle(amd, N, K, planes, steps=9, budget=1e9, max_days=4, loss_threshold=30.0, auto_reset=True,
+                   bid_lo=0.8, bid_hi=1.4)
+
+
+def test_drift_matches_oracle(amd):
+    N, K = 5, 200
+    planes = H.implicit_params(N, K, seed=14)
+    _run_vs_oracle(amd, N, K, planes, steps=5, budget=1e9, drift=True, check_params=True)
+    _run_vs_oracle(amd, N, K, planes, steps=4, budget=40.0, drift=True, check_params=True)
+
+
+# ------------------------------------------------------------------ EXPLICIT model (default constructor)
+@pytest.mark.parametrize("budget", [1000.0, 6.0])
+def test_explicit_matches_oracle(amd, budget):
+    N, K = 3, 64
+    planes = H.explicit_params(N, K, seed=15)
+    _run_vs_oracle(amd, N, K, planes, steps=3, budget=budget, model=1, bid_lo=0.05, bid_hi=2.0)
+
+
+def test_explicit_drift(amd):
+    planes = H.explicit_params(2, 10, seed=16)
+    _run_vs_oracle(amd, 2, 10, planes, steps=3, budget=1000.0, model=1, drift=True, check_params=True)
+
+
+# ------------------------------------------------------------------ TAPE mode: the reference's own traces
+def test_g3_implicit_replay_on_gpu(amd, golden):
+    for t in golden("g3_implicit_replay.json")["traces"]:
+        K = t["K"]
+        e = amd.StepEngine(1, K, seed=1)
+        e.reset()
+        tp = t["tape"]
+        tape = amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), bid_cents=tp["bid"], click=tp["click"],
+                              conv=tp["conv"], rev_cents=tp["rev"])
+        out = e.step_replay(np.array(t["bids"], np.float32), t["budget"], tape)
+        ref = t["out"]
+        assert out["impressions"][0].tolist() == ref["impressions"]
+        assert out["buyside_clicks"][0].tolist() == ref["buyside_clicks"]
+        assert out["sellside_conversions"][0].tolist() == ref["sellside_conversions"]
+        assert np.array_equal(out["cost"][0], np.array(ref["cost"]).astype(np.float32))
+        assert np.array_equal(out["revenue"][0], np.array(ref["revenue"]).astype(np.float32))
+        np.testing.assert_allclose(out["reward"][0], sum(ref["profit"]), rtol=0, atol=1e-9)
+        assert (tape.end["bid"][0], tape.end["click"][0], tape.end["conv"][0], tape.end["rev"][0]) == \
+            (len(tp["bid"]), len(tp["click"]), len(tp["conv"]), len(tp["rev"]))
+        e.close()
+
+
+def test_g3_explicit_replay_on_gpu(amd, golden):
+    for t in golden("g3_explicit_replay.json")["traces"]:
+        K = t["K"]
+        e = amd.StepEngine(1, K, model=1, seed=1)
+        e.reset()
+        tp = t["tape"]
+        tape = amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), click=tp["click"], conv=tp["conv"],
+                              rev_cents=tp["rev"], x_impressions=tp["impressions"], x_cost=tp["cost"])
+        out = e.step_replay(np.array(t["bids"], np.float32), t["budget"], tape)
+        ref = t["out"]
+        assert out["impressions"][0].tolist() == ref["impressions"]
+        assert out["buyside_clicks"][0].tolist() == ref["buyside_clicks"]
+        assert out["sellside_conversions"][0].tolist() == ref["sellside_conversions"]
+        assert np.array_equal(out["cost"][0], np.array(ref["cost"]).astype(np.float32))     # f64 sum in reference order
+        np.testing.assert_allclose(out["reward"][0], sum(ref["profit"]), rtol=0, atol=1e-9)
+        assert tape.end["xcost"][0] == len(tp["cost"]) and tape.end["click"][0] == len(tp["click"])
+        e.close()
+
+
+def test_g8_env_episodes_on_gpu(amd, golden):
+    for ep in golden("g8_env_episodes.json")["episodes"]:
+        K = ep["K"]
+        e = amd.StepEngine(1, K, seed=1, max_days=ep["max_days"], loss_threshold=ep["loss_threshold"])
+        e.reset()
+        tp = ep["tape"]
+        for i, st in enumerate(ep["steps"]):
+            sl = st["tape_slices"]
+            tape = amd.ReplayTape(1, np.array(st["volumes"]).reshape(1, K), bid_cents=tp["bid"], click=tp["click"],
+                                  conv=tp["conv"], rev_cents=tp["rev"],
+                                  offsets={k: [sl[k][0]] for k in ("bid", "click", "conv", "rev")})
+            out = e.step_replay(np.array(st["bids"], np.float32), st["budget"], tape)
+            ob = st["obs"]
+            assert out["impressions"][0].tolist() == ob["impressions"]
+            assert out["buyside_clicks"][0].tolist() == ob["buyside_clicks"]
+            assert out["sellside_conversions"][0].tolist() == ob["sellside_conversions"]
+            assert np.array_equal(out["cost"][0], np.array(ob["cost"]).astype(np.float32))
+            np.testing.assert_allclose(out["reward"][0], st["reward"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(out["cumulative_profit"][0], ob["cumulative_profit"][0], rtol=0, atol=1e-9)
+            assert out["days_passed"][0] == i + 1
+            assert bool(out["terminated"][0]) == st["terminated"] and bool(out["truncated"][0]) == st["truncated"]
+            assert tape.end["bid"][0] == sl["bid"][1] and tape.end["rev"][0] == sl["rev"][1]
+        e.close()
+
+
+def test_g1_nth_price_auction_on_gpu(amd, golden):
+    import ctypes as C
+    from adcraft_amd import _ffi
+    L = _ffi.lib()
+    for c in golden("g1_nth_price_auction.json")["cases"]:
+        ob = np.array(c["other_bids"], dtype=np.float64)
+        ob = ob.reshape(len(c["other_bids"]), -1) if len(c["other_bids"]) else np.zeros((0, 1))
+        na, nb = ob.shape
+        pl = np.zeros(max(na, 1), np.int32)
+        co = np.zeros(max(na, 1), np.float64)
+        imp = C.c_int32()
+        _ffi.check(L.adc_nth_price_auction(0, c["bid"], ob.ctypes.data, na, nb, c["n"], c["num_winners"], C.byref(imp),
+                                           pl.ctypes.data, co.ctypes.data))
+        assert imp.value == c["impressions"], c["tag"]
+        assert pl[:imp.value].tolist() == c["placements"], c["tag"]
+        assert co[:imp.value].tolist() == c["costs"], c["tag"]
+
+
+# ------------------------------------------------------------------ stream properties
+def test_results_do_not_depend_on_sharding(amd):
+    """envs [0,8) on one engine == envs [0,4) + [4,8) on two engines with env_id_base (multi-GPU invariant)"""
+    N, K = 8, 96
+    planes = H.implicit_params(N, K, seed=21)
+    bids = np.random.default_rng(1).uniform(0.3, 1.0, (N, K)).astype(np.float32)
+    whole = amd.StepEngine(N, K, seed=99)
+    whole.set_all_params(planes)
+    whole.reset()
+    a = whole.step(bids, 1e9)
+    parts = []
+    for base in (0, 4):
+        e = amd.StepEngine(4, K, seed=99, env_id_base=base)
+        e.set_all_params(planes[:, base:base + 4])
+        e.reset()
+        parts.append(e.step(bids[base:base + 4], 1e9))
+        e.close()
+    for k in a:
+        assert np.array_equal(a[k], np.concatenate([p[k] for p in parts])), k
+    whole.close()
+
+
+def test_synthetic_actions_match_oracle(amd):
+    N, K = 3, 130
+    e = amd.StepEngine(N, K, seed=5)
+    e.reset()
+    o = H.mirror_oracle(e, H.implicit_params(N, K, 1))
+    e.sample_actions(0.3, 1.0, 1e9)
+    e.synchronize()
+    import ctypes as C
+    from adcraft_amd import _ffi
+    p, nbytes = e.device_buffer(_ffi.BUF_BIDS)
+    assert nbytes == N * K * 4
+    # read the staging buffer back through a step: the bids the engine used are the oracle's
+    e.set_all_params(o.params)
+    e.step_device()
+    got = e.fetch()
+    ref = o.step(o.sample_bids(0.3, 1.0), 1e9)
+    H.assert_step_equal(got, ref)
+    e.close()
+
+
+def test_step_before_reset_raises(amd):
+    e = amd.StepEngine(1, 4)
+    with pytest.raises(AssertionError):
+        e.step(np.ones((1, 4), np.float32), 10.0)
+    e.close()
+
+
+# ------------------------------------------------------------------ BASELINE full size: size-independent properties
+def test_full_size_cfg2_properties(amd):
+    N, K = 4096, 256
+    planes = H.implicit_params(N, K, seed=1730)
+    e = amd.StepEngine(N, K, seed=1730)
+    e.set_all_params(planes)
+    e.reset()
+    k0, t0 = e.get_rng_state()
+    e.sample_actions(0.3, 1.0, 1e9)
+    e.step_device()
+    a = e.fetch()
+    assert (a["buyside_clicks"] <= a["impressions"]).all()
+    assert (a["sellside_conversions"] <= a["buyside_clicks"]).all()
+    assert (a["cost"][a["buyside_clicks"] == 0] == 0).all() and (a["revenue"][a["sellside_conversions"] == 0] == 0).all()
+    assert (a["impressions"] <= 128 + 6 * 65).all() and a["impressions"].mean() > 20
+    cents = np.rint(a["revenue"].astype(np.float64) * 100) - np.rint(a["cost"].astype(np.float64) * 100)
+    assert np.array_equal(np.rint(a["reward"] * 100), cents.sum(axis=1))          # checksum of checksums
+    assert (a["days_passed"] == 1).all() and not a["terminated"].any()
+    # idempotence: same stream state + same actions -> identical step
+    e.set_rng_state(k0, t0)
+    e.set_episode_state(np.zeros(N, np.int32), np.zeros(N))
+    e.sample_actions(0.3, 1.0, 1e9)
+    e.step_device()
+    b = e.fetch()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # a slice of the big launch equals the oracle on the same envs
+    sub = slice(100, 104)
+    e.set_rng_state(k0, t0)
+    from oracle import capi as orc
+    o = orc.OracleEngine(4, K)
+    o.params[:] = planes[:, sub]
+    o.key[:] = k0[sub]
+    o.tick[:] = t0[sub]
+    ref = o.step(o.sample_bids(0.3, 1.0), 1e9)
+    assert np.array_equal(a["impressions"][sub], ref["impressions"])
+    assert np.array_equal(a["buyside_clicks"][sub], ref["clicks"])
+    assert np.array_equal(a["reward"][sub], ref["reward"])
+    e.close()

