@@ -441,7 +441,8 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                 const float bid_d = (float)((double)bid_c / 100.0);
                 const float p_imp = orc_threshold_sigmoid_f32(bid_d, c->imp_thresh, P(s, c, P_A, env, k), P(s, c, P_B, env, k));
                 const uint64_t t_imp = orc_bernoulli_threshold(p_imp);
-                double budget = remaining_d, cell_cost_sum = 0.0, cell_rev = 0.0;
+                double budget = remaining_d, cell_cost_sum = 0.0;
+                int64_t cell_rev_c = 0;        /* revenues are whole cents: summed exactly, converted once per cell */
                 int32_t imps = 0, paid = 0, convs = 0;
                 int broke = 0;
                 int32_t n_imp_tape = use_tape ? tape->x_impressions[tape->cur_ximp++] : -1;
@@ -472,7 +473,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                             }
                             ++convs;
                             o->revenue_cents[base + k] += rev;
-                            cell_rev += (double)rev / 100.0;
+                            cell_rev_c += rev;
                         }
                     } else broke = 1;
                 }
@@ -490,14 +491,14 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                                                    : orc_revenue_cents_from_word(w[2], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
-                            cell_rev += (double)rev / 100.0;
+                            cell_rev_c += rev;
                         }
                     }
                 }
                 o->impressions[base + k] += imps;
                 o->clicks[base + k] += paid;
                 o->conversions[base + k] += convs;
-                profit_k[k] += cell_rev - cell_cost_sum;        /* combine_outcomes: profit += profit */
+                profit_k[k] += (double)cell_rev_c / 100.0 - cell_cost_sum;        /* combine_outcomes: profit += profit */
                 remaining_d -= cell_cost_sum;
                 if (remaining_d <= 0.0) stop = 1;
             }
