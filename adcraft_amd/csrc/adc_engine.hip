@@ -158,14 +158,17 @@ __device__ __forceinline__ void drift_keyword(const View &v, uint64_t key, uint3
 // -------------------------------------------------------------------------------------------------
 // FAST PASS (IMPLICIT, engine stream, budget ignored)
 // -------------------------------------------------------------------------------------------------
+constexpr int kQueueCap = 256;    // per-wave ring of deferred paid clicks (entries), power of two
+
 struct FastShared {
     int off[kFastBlock];            // exclusive prefix of chunk counts
     int vol[kFastBlock];
     int bid_c[kFastBlock];
     float loc[kFastBlock], scale[kFastBlock], mu[kFastBlock], sd[kFastBlock];
-    float bctr[kFastBlock], sctr[kFastBlock];
+    unsigned long long t_click[kFastBlock], t_conv[kFastBlock];       // Bernoulli thresholds
     unsigned int a_imp[kFastBlock], a_clk[kFastBlock], a_conv[kFastBlock];
     unsigned long long a_cost[kFastBlock], a_rev[kFastBlock];
+    unsigned int queue[kFastBlock / kWave][kQueueCap];
     int wave_tot[kFastBlock / kWave];
     long long red[2][kFastBlock / kWave];
 };
@@ -201,8 +204,8 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         sh.scale[tid] = param_at(v, ADC_P_B, env, k);
         sh.mu[tid] = param_at(v, ADC_P_REV_MEAN, env, k);
         sh.sd[tid] = param_at(v, ADC_P_REV_STD, env, k);
-        sh.bctr[tid] = bctr;
-        sh.sctr[tid] = sctr;
+        sh.t_click[tid] = adc::bernoulli_threshold(bctr);
+        sh.t_conv[tid] = adc::bernoulli_threshold(sctr);
         sh.bid_c[tid] = (int)adc::bid_to_cents(bids[(size_t)env * v.K + k]);
         const adc::U4 w = adc::draw(key, 0u, adc::ST_VOL, (uint32_t)k, tick);
         V = adc::volume_from_word(w.x, vol_mean, vol_std);
@@ -225,42 +228,80 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
     __syncthreads();
 
     // ---- phase 2: chunks of kChunk auctions, dealt round-robin ----------------------------------
-    for (int item = tid; item < total; item += kFastBlock) {
-        int u = 0;
-#pragma unroll
-        for (int s = kFastBlock / 2; s > 0; s >>= 1)
-            if (sh.off[u + s] <= item) u += s;
-        const int j0 = (item - sh.off[u]) * kChunk;
-        const int n = min(kChunk, sh.vol[u] - j0);
-        const int bid_c = sh.bid_c[u];
-        const float loc = sh.loc[u], scale = sh.scale[u], mu = sh.mu[u], sd = sh.sd[u];
-        const uint64_t t_click = adc::bernoulli_threshold(sh.bctr[u]);
-        const uint64_t t_conv = adc::bernoulli_threshold(sh.sctr[u]);
-        const uint32_t kw = (uint32_t)(tile * kFastBlock + u);
-        unsigned int imp = 0, clk = 0, cv = 0;
-        unsigned long long cost = 0, rev = 0;
-        for (int i = 0; i < n; ++i) {
-            const adc::U4 w = adc::draw(key, (uint32_t)(j0 + i), adc::ST_AUCTION, kw, tick);
-            const int comp = adc::laplace_cents(w.x, loc, scale);
-            const bool win = bid_c > comp;                                 // tie loses (helpers.py:167-170)
-            const bool click = win && adc::bernoulli(w.y, t_click);
-            const bool conv = click && adc::bernoulli(w.z, t_conv);
-            imp += win;
-            clk += click;
-            cost += click ? (unsigned long long)comp : 0ull;               // 2nd price = the competitor's bid
-            cv += conv;
-            if (conv) rev += (unsigned long long)adc::revenue_cents(w.w, mu, sd);
+    // Control flow is wave-uniform (idle lanes carry n = 0) so that the deferred-click ring below can
+    // be maintained with ballots.  Stage A (every auction): one Philox call per PAIR of auctions ->
+    // competitor bid, 2nd-price clearing, click.  Stage B (paid clicks only, ~1/4 of auctions): the
+    // click's (keyword, auction) is pushed to a per-wave LDS ring; whenever 64 are waiting, all 64
+    // lanes draw the conversion/revenue call together - so the expensive normal-quantile runs on
+    // full wavefronts instead of on the ~20 % of lanes that happen to convert.
+    unsigned int *const ring = sh.queue[wv];
+    unsigned int qhead = 0, qtail = 0;
+    const unsigned long long lt = lanemask_lt();
+    const uint32_t kw_base = (uint32_t)(tile * kFastBlock);
+
+    auto resolve_click = [&](unsigned int pos) {
+        const unsigned int ent = ring[pos & (kQueueCap - 1)];
+        const unsigned int uu = ent >> 24;
+        const adc::U4 w2 = adc::draw(key, ent & 0x00FFFFFFu, adc::ST_CONV, kw_base + uu, tick);
+        if (adc::bernoulli(w2.x, sh.t_conv[uu])) {
+            const int rv = adc::revenue_cents(w2.y, sh.mu[uu], sh.sd[uu]);
+            atomicAdd(&sh.a_conv[uu], 1u);
+            atomicAdd(&sh.a_rev[uu], (unsigned long long)rv);
         }
-        atomicAdd(&sh.a_imp[u], imp);
+    };
+
+    const int rounds = (total + kFastBlock - 1) / kFastBlock;
+    for (int r = 0; r < rounds; ++r) {
+        const int item = r * kFastBlock + tid;
+        int u = 0, j0 = 0, n = 0;
+        if (item < total) {
+#pragma unroll
+            for (int s = kFastBlock / 2; s > 0; s >>= 1)
+                if (sh.off[u + s] <= item) u += s;
+            j0 = (item - sh.off[u]) * kChunk;
+            n = min(kChunk, sh.vol[u] - j0);
+        }
+        const int bid_c = sh.bid_c[u];
+        const float loc = sh.loc[u], scale = sh.scale[u];
+        const unsigned long long t_click = sh.t_click[u];
+        const uint32_t kw = kw_base + (uint32_t)u;
+        const unsigned int tag = (unsigned int)u << 24;
+        unsigned int imp = 0, clk = 0;
+        unsigned long long cost = 0;
+        for (int i = 0; i < kChunk; i += 2) {
+            const bool a0 = i < n, a1 = i + 1 < n;
+            if (!__any(a0)) break;
+            const adc::U4 w = adc::draw(key, (uint32_t)(j0 + i) >> 1, adc::ST_AUCTION, kw, tick);
+            const int comp0 = adc::laplace_cents(w.x, loc, scale);
+            const int comp1 = adc::laplace_cents(w.z, loc, scale);
+            const bool win0 = a0 && bid_c > comp0;                          // tie loses (helpers.py:167-170)
+            const bool win1 = a1 && bid_c > comp1;
+            const bool click0 = win0 && adc::bernoulli(w.y, t_click);
+            const bool click1 = win1 && adc::bernoulli(w.w, t_click);
+            imp += (unsigned int)win0 + (unsigned int)win1;
+            clk += (unsigned int)click0 + (unsigned int)click1;
+            cost += (click0 ? (unsigned long long)comp0 : 0ull) + (click1 ? (unsigned long long)comp1 : 0ull);  // 2nd price
+            const unsigned long long m0 = __ballot(click0), m1 = __ballot(click1);
+            if (click0) ring[(qtail + __popcll(m0 & lt)) & (kQueueCap - 1)] = tag | (unsigned int)(j0 + i);
+            qtail += __popcll(m0);
+            if (click1) ring[(qtail + __popcll(m1 & lt)) & (kQueueCap - 1)] = tag | (unsigned int)(j0 + i + 1);
+            qtail += __popcll(m1);
+            while (qtail - qhead >= (unsigned int)kWave) {      // <= 63 + 128 entries can be waiting (ring holds 256)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                resolve_click(qhead + lane);
+                qhead += kWave;
+            }
+        }
+        if (imp) atomicAdd(&sh.a_imp[u], imp);
         if (clk) {
             atomicAdd(&sh.a_clk[u], clk);
             atomicAdd(&sh.a_cost[u], cost);
         }
-        if (cv) {
-            atomicAdd(&sh.a_conv[u], cv);
-            atomicAdd(&sh.a_rev[u], rev);
-        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((unsigned int)lane < qtail - qhead) resolve_click(qhead + lane);      // fewer than 64 left
     __syncthreads();
 
     // ---- phase 3: outputs ---------------------------------------------------------------------
@@ -390,13 +431,15 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
                     for (int base = 0; base < n; base += kWave) {
                         const int i = base + lane;
                         const bool act = i < n;
-                        adc::U4 w{0u, 0u, 0u, 0u};
+                        uint32_t wclick = 0;
                         long long comp = 0;
+                        const uint32_t j = (uint32_t)(j0 + i);
                         if (act) {
                             if (TAPE) comp = tp.bid_cents[cur_bid + i];
                             else {
-                                w = adc::draw(key, (uint32_t)(j0 + i), adc::ST_AUCTION, (uint32_t)k, tick);
-                                comp = adc::laplace_cents(w.x, loc, scale);
+                                const adc::U4 w = adc::draw(key, j >> 1, adc::ST_AUCTION, (uint32_t)k, tick);
+                                comp = adc::laplace_cents((j & 1u) ? w.z : w.x, loc, scale);
+                                wclick = (j & 1u) ? w.w : w.y;
                             }
                         }
                         const bool win = act && bid_c > comp;
@@ -404,7 +447,7 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
                         bool clicked = false;
                         if (win) {
                             if (TAPE) clicked = tp.click[cur_click + wins + __popcll(win_mask & lt)] != 0;
-                            else clicked = adc::bernoulli(w.y, t_click);
+                            else clicked = adc::bernoulli(wclick, t_click);
                         }
                         // budget walk (bidding_simulation.py:97-104): click i is paid iff the running
                         // sum of clicked costs up to and including it fits the cell's opening budget
@@ -413,16 +456,17 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
                         const bool is_paid = clicked && pre <= remaining_c;
                         const unsigned long long paid_mask = __ballot(is_paid);
                         bool convd = false;
+                        long long rv = 0;
                         if (is_paid) {
                             if (TAPE) convd = tp.conv[cur_conv + paid + __popcll(paid_mask & lt)] != 0;
-                            else convd = adc::bernoulli(w.z, t_conv);
+                            else {
+                                const adc::U4 w2 = adc::draw(key, j, adc::ST_CONV, (uint32_t)k, tick);
+                                convd = adc::bernoulli(w2.x, t_conv);
+                                if (convd) rv = adc::revenue_cents(w2.y, mu, sd);
+                            }
                         }
                         const unsigned long long conv_mask = __ballot(convd);
-                        long long rv = 0;
-                        if (convd) {
-                            if (TAPE) rv = tp.rev_cents[cur_rev + convs + __popcll(conv_mask & lt)];
-                            else rv = adc::revenue_cents(w.w, mu, sd);
-                        }
+                        if (TAPE && convd) rv = tp.rev_cents[cur_rev + convs + __popcll(conv_mask & lt)];
                         clicked_sum += wave_sum_i64(x);
                         cell_cost += wave_sum_i64(is_paid ? comp : 0);
                         cell_rev += wave_sum_i64(rv);

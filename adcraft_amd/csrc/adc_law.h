@@ -28,19 +28,32 @@
 
 namespace adc {
 
-enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6 };
+// IMPLICIT: call (j/2, ST_AUCTION) = {bid, click} words of auction j even (x,y) and j odd (z,w);
+//           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
+// EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
+//           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
+enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
 constexpr int kTimesteps = 24;          // adcraft/bidding_simulation.py:213
 constexpr int kVolumeMax = 1 << 20;
 constexpr float kMoneyMaxCents = 1.0e9f;
 
 struct U4 { uint32_t x, y, z, w; };
 
+ADC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);      // one VALU op on gfx950
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 ADC_HD void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
 {
-    const uint64_t a = (uint64_t)0xD2511F53u * c0;
+    const uint64_t a = (uint64_t)0xD2511F53u * c0;          // v_mad_u64_u32: both halves in one op
     const uint64_t b = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(b >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(a >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = xor3((uint32_t)(b >> 32), c1, k0);
+    const uint32_t n2 = xor3((uint32_t)(a >> 32), c3, k1);
     c1 = (uint32_t)b;
     c3 = (uint32_t)a;
     c0 = n0;

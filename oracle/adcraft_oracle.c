@@ -48,7 +48,9 @@
 enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1 };
 enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT };
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
-enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6 };
+enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
+/* IMPLICIT stream layout: call (j/2, ST_AUCTION) holds {bid, click} words of auctions j even (x,y) and j odd (z,w);
+ * call (j, ST_CONV) holds {conversion, revenue} words (x,y) of auction j and is only consumed for a paid click. */
 #define ORC_TIMESTEPS 24
 #define ORC_VMAX (1 << 20)
 
@@ -407,23 +409,29 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                 /* pass 1: the auctions (impressions are not budget-limited, :86-88) */
                 int64_t click_cur = tape ? tape->cur_click : 0;
                 for (int32_t i = 0; i < n; ++i) {
-                    uint32_t w[4] = {0, 0, 0, 0};
+                    uint32_t wb = 0, wc = 0;                       /* bid word, click word of auction j0+i */
+                    const uint32_t j = (uint32_t)(j0 + i);
                     int64_t comp;
                     if (use_tape) comp = tape->bid_cents[tape->cur_bid++];
                     else {
-                        draw(key, (uint32_t)(j0 + i), ST_AUCTION, (uint32_t)k, tick, w);
-                        comp = orc_laplace_cents_from_word(w[0], loc, scale);
+                        uint32_t w[4];
+                        draw(key, j >> 1, ST_AUCTION, (uint32_t)k, tick, w);
+                        wb = (j & 1u) ? w[2] : w[0];
+                        wc = (j & 1u) ? w[3] : w[1];
+                        comp = orc_laplace_cents_from_word(wb, loc, scale);
                     }
                     if (!(bid_c > comp)) continue;             /* tie loses, helpers.py:167-170 */
                     ++wins;
-                    int clicked = use_tape ? tape->click[click_cur + wins - 1] : ((uint64_t)w[1] < t_click);
+                    int clicked = use_tape ? tape->click[click_cur + wins - 1] : ((uint64_t)wc < t_click);
                     if (!clicked || broke) continue;
                     if (budget >= comp) {                      /* :97-104 */
                         budget -= comp; cell_cost += comp; ++paid;
-                        int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w[2] < t_conv);
+                        uint32_t w2[4] = {0, 0, 0, 0};
+                        if (!use_tape) draw(key, j, ST_CONV, (uint32_t)k, tick, w2);
+                        int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w2[0] < t_conv);
                         if (conv) {
                             int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
-                                                   : orc_revenue_cents_from_word(w[3], rev_mu, rev_sd);
+                                                   : orc_revenue_cents_from_word(w2[1], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
                         }
