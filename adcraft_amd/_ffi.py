@@ -72,6 +72,8 @@ def lib():
         "adc_engine_get_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_set_env_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_reset": ([vp, vp, vp], C.c_int),
+        "adc_engine_set_limits": ([vp, i32, f64], C.c_int),
+        "adc_engine_set_drift": ([vp, i32, f32, f32, f32], C.c_int),
         "adc_engine_get_rng_state": ([vp, vp, vp], C.c_int),
         "adc_engine_set_rng_state": ([vp, vp, vp], C.c_int),
         "adc_engine_get_episode_state": ([vp, vp, vp], C.c_int),

@@ -1038,6 +1038,31 @@ ADC_EXPORT int adc_engine_reset(adc_engine *e, const uint8_t *env_mask, const ui
     return ADC_OK;
 }
 
+ADC_EXPORT int adc_engine_set_limits(adc_engine *e, int32_t max_days, double loss_threshold)
+{
+    ENGINE_GUARD(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->v.max_days = max_days;
+    e->v.loss_threshold = loss_threshold;
+    e->cfg.max_days = max_days;
+    e->cfg.loss_threshold = loss_threshold;
+    return ADC_OK;
+}
+
+ADC_EXPORT int adc_engine_set_drift(adc_engine *e, int32_t enabled, float drift_vol, float drift_ctr, float drift_cvr)
+{
+    ENGINE_GUARD(e);
+    if (!enabled && e->v.drift_on) {      // apply what is pending under the old setting, then switch off
+        hipLaunchKernelGGL(k_materialize_drift, dim3(e->v.N), dim3(256), 0, e->stream, e->v);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->v.drift_on = enabled ? 1 : 0;
+    e->v.drift_vol = drift_vol; e->v.drift_ctr = drift_ctr; e->v.drift_cvr = drift_cvr;
+    if (!enabled) HIP_TRY(hipMemsetAsync(e->v.drift_pending, 0, (size_t)e->v.N, e->stream));
+    return ADC_OK;
+}
+
 ADC_EXPORT int adc_engine_get_rng_state(adc_engine *e, uint64_t *keys_n, uint32_t *ticks_n)
 {
     ENGINE_GUARD(e);

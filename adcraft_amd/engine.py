@@ -82,6 +82,12 @@ class StepEngine:
             raise ValueError("seeds must have shape (num_envs,)")
         check(self._lib.adc_engine_reset(self._h, ptr(m), ptr(s)))
 
+    def set_limits(self, max_days, loss_threshold):
+        check(self._lib.adc_engine_set_limits(self._h, int(max_days), float(loss_threshold)))
+
+    def set_drift(self, enabled, drift=(0.03, 0.03, 0.03)):
+        check(self._lib.adc_engine_set_drift(self._h, 1 if enabled else 0, float(drift[0]), float(drift[1]), float(drift[2])))
+
     def get_rng_state(self):
         k = np.zeros(self.num_envs, dtype=np.uint64)
         t = np.zeros(self.num_envs, dtype=np.uint32)

@@ -152,6 +152,11 @@ int adc_engine_set_env_params(adc_engine *e, int env, const float *host_8k);
  * seeds (nullable, [N]) re-key the env's random stream (reset(seed=...)); gymnasium_kw_env.py:271-346 */
 int adc_engine_reset(adc_engine *e, const uint8_t *env_mask, const uint64_t *seeds);
 
+/* reset(options={"max_days":..., "loss_threshold":...}) and set_updater_mask()/updater_params changes
+ * (gymnasium_kw_env.py:105-112,318-325) */
+int adc_engine_set_limits(adc_engine *e, int32_t max_days, double loss_threshold);
+int adc_engine_set_drift(adc_engine *e, int32_t enabled, float drift_vol, float drift_ctr, float drift_cvr);
+
 /* random-stream state of every env: Philox key [N] and step counter ("tick") [N]; with the episode state
  * below this is everything needed to checkpoint / resume an engine (the parameters come from get_params) */
 int adc_engine_get_rng_state(adc_engine *e, uint64_t *keys_n, uint32_t *ticks_n);

@@ -1,0 +1,200 @@
+"""-m gpu: the drop-in Python surface (BiddingSimulation, vector env, adaptors) on a real device.
+The first block mirrors the reference's own env tests (adcraft/tests/test_env.py:10-69)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import adcraft_amd
+    from adcraft_amd import _ffi
+    assert _ffi.device_count() >= 1
+    return adcraft_amd
+
+
+def _cfg(mv=128, cvr=0.8, **kw):
+    from adcraft_amd import gymnasium_kw_utils as utils
+    return utils.experiment_keyword_config(mv, cvr, **kw)
+
+
+# ---------------------------------------------------------------- adcraft/tests/test_env.py
+def test_reference_env_tests(pkg):
+    env = pkg.BiddingSimulation()
+    try:
+        import gymnasium as gym
+        assert isinstance(env, gym.Env)
+    except ImportError:
+        pass
+    assert hasattr(env, "observation_space") and hasattr(env, "action_space")
+    for s in (None, 1):
+        env.reset(seed=s)
+    reset_obs, reset_info = env.reset()
+    assert env.observation_space.contains(reset_obs)
+    assert "keyword_params" in reset_info
+    action = env.action_space.sample()
+    next_obs, reward, done, truncated, info = env.step(action)
+    for k, v in reset_obs.items():
+        next_obs[k] = next_obs[k].astype(v.dtype)
+    assert env.observation_space.contains(next_obs)
+    assert isinstance(reward, float) and isinstance(done, bool) and isinstance(truncated, bool)
+    assert set(info) == {"bids", "bidding_outcomes", "keyword_params"}
+    assert str(info["bidding_outcomes"]).startswith("[{'bid':") and "kw0 params" in str(info["keyword_params"])
+    env.close()
+
+
+def test_reset_seed_reproduces_reference_keywords(pkg, golden):
+    kat = golden("g2_keyword_params.json")["notebook_kat"]
+    env = pkg.BiddingSimulation(keyword_config=_cfg(100, 0.3), num_keywords=30)
+    env.reset(seed=10)
+    p = env.keyword_params[0]
+    assert [list(map(float, p[0]))] + [float(x) for x in p[1:]] == [[100.0, 13.0]] + kat["seed10_kw0"][1:]
+    assert len(env.keywords) == 30 and env.keywords[0].buyside_ctr == p[3]
+    assert env.keywords[0].sample_bids(2048).shape == (1, 2048)
+    env.close()
+
+
+def test_same_seed_same_trajectory_and_matches_oracle(pkg):
+    from oracle import capi as orc
+    K = 24
+    bids = np.round(np.random.default_rng(0).uniform(0.3, 1.1, (6, K)), 2)
+
+    def run(seed):
+        env = pkg.BiddingSimulation(keyword_config=_cfg(64, 0.8), num_keywords=K, budget=40.0, max_days=6)
+        env.reset(seed=seed)
+        o = orc.OracleEngine(1, K, max_days=6)
+        o.params[:] = env._engine.get_all_params()
+        o.key[:], o.tick[:] = env._engine.get_rng_state()
+        traj = []
+        for t in range(6):
+            obs, r, term, trunc, info = env.step({"keyword_bids": bids[t].astype(np.float32), "budget": np.float32(40.0)})
+            ref = o.step(bids[t].astype(np.float32), 40.0)
+            assert obs["impressions"].tolist() == ref["impressions"][0].tolist()
+            assert obs["buyside_clicks"].tolist() == ref["clicks"][0].tolist()
+            assert r == ref["reward"][0] and term == bool(ref["terminated"][0])
+            assert abs(obs["cost"].sum() - 40.0) < 40.0 + 1e-6
+            traj.append((obs["impressions"].tolist(), obs["sellside_conversions"].tolist(), r))
+        assert term and env.current_day == 6
+        env.close()
+        return traj
+    a, b, c = run(3), run(3), run(4)
+    assert a == b and a != c
+
+
+def test_options_truncation_render(pkg):
+    env = pkg.BiddingSimulation(keyword_config=_cfg(64, 0.1), num_keywords=8, render_mode="ansi")
+    env.reset(seed=2, options={"max_days": 3, "loss_threshold": 5.0})
+    assert env.max_days == 3 and env.loss_threshold == 5.0
+    obs, r, term, trunc, info = env.step({"keyword_bids": np.full(8, 1.5, np.float32)})
+    assert trunc and r < -5.0 and env.cumulative_profit == pytest.approx(r)
+    txt = env.render()
+    assert txt.startswith("Time step: 1/3") and "truncated early" in txt
+    assert info["bids"] == [1.5] * 8
+    obs0, _ = env.reset()
+    assert env.current_day == 0 and env.cumulative_profit == 0.0
+    env.close()
+
+
+def test_drift_keyword_params_follow_device(pkg):
+    from oracle import capi as orc
+    K = 12
+    env = pkg.BiddingSimulation(keyword_config=_cfg(128, 0.8), num_keywords=K, updater_mask=[True] * K,
+                                updater_params=[["vol", 0.05], ["ctr", 0.1], ["cvr", 0.2]])
+    env.reset(seed=9)
+    p0 = [list(p) for p in env.keyword_params]
+    o = orc.OracleEngine(1, K, drift=(0.05, 0.1, 0.2), drift_on=True)
+    o.params[:] = env._engine.get_all_params()
+    o.key[:], o.tick[:] = env._engine.get_rng_state()
+    for t in range(3):
+        b = np.full(K, 0.8, np.float32)
+        env.step({"keyword_bids": b})
+        o.step(b, 1000.0)
+    o.materialize_drift()
+    p = env.keyword_params
+    assert [q[0][0] for q in p] == [float(x) for x in o.params[orc.P_VOL_MEAN, 0]]
+    assert [q[3] for q in p] == [float(x) for x in o.params[orc.P_BCTR, 0]]
+    assert [q[0][1] for q in p] == [q[0][1] for q in p0] and any(q[3] != q0[3] for q, q0 in zip(p, p0))
+    env.update_keywords()                       # direct call, as the reference allows
+    assert any(q[3] != float(x) for q, x in zip(env.keyword_params, o.params[orc.P_BCTR, 0]))
+    env.close()
+
+
+def test_default_constructor_is_explicit_model_with_phantom_clicks(pkg):
+    env = pkg.BiddingSimulation(num_keywords=64)        # BASELINE cfg1 shape: default config, 1 env x 64 keywords
+    env.reset(seed=0)
+    tot_c = tot_i = 0
+    for _ in range(5):
+        obs, r, term, trunc, _ = env.step({"keyword_bids": np.full(64, 0.05, np.float32)})
+        tot_c += obs["buyside_clicks"].sum()
+        tot_i += obs["impressions"].sum()
+    assert tot_c > tot_i        # zero-impression sub-steps still yield phantom clicks (SURVEY B-1)
+    env.close()
+
+
+# ---------------------------------------------------------------- vector env
+def test_vector_env_matches_single_envs(pkg):
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    N, K = 6, 16
+    vec = BiddingSimulationVectorEnv(N, keyword_config=_cfg(64, 0.8), num_keywords=K, max_days=3)
+    obs, _ = vec.reset(seed=50)
+    assert obs["impressions"].shape == (N, K) and obs["cumulative_profit"].shape == (N, 1)
+    bids = np.round(np.random.default_rng(1).uniform(0.3, 1.0, (N, K)), 2).astype(np.float32)
+    vobs, rew, term, trunc, infos = vec.step({"keyword_bids": bids, "budget": np.full(N, 1000.0, np.float32)})
+    for i in (0, 3, 5):      # env i == a single BiddingSimulation reset with seed 50 + i
+        env = pkg.BiddingSimulation(keyword_config=_cfg(64, 0.8), num_keywords=K, max_days=3)
+        env.reset(seed=50 + i)
+        sobs, r, *_ = env.step({"keyword_bids": bids[i]})
+        assert sobs["impressions"].tolist() == vobs["impressions"][i].tolist()
+        assert sobs["revenue"].tolist() == vobs["revenue"][i].tolist() and r == rew[i]
+        env.close()
+    vec.step({"keyword_bids": bids})
+    vobs, rew, term, trunc, infos = vec.step({"keyword_bids": bids})
+    assert term.all() and infos["_final_obs"].all() and (infos["final_obs"]["days_passed"] == 3).all()
+    vobs, *_ = vec.step({"keyword_bids": bids})
+    assert (vobs["days_passed"] == 1).all()          # autoreset restarted the episodes
+    vec.close()
+
+
+def test_flat_layout_and_adaptors(pkg):
+    from adcraft_amd import gymnasium_kw_utils as utils
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv, RLlibVectorEnvAdapter, SB3VecEnvAdapter
+    N, K = 4, 8
+    mk = lambda flat: BiddingSimulationVectorEnv(N, keyword_config=_cfg(64, 0.8), num_keywords=K, flat=flat, max_days=2)  # noqa: E731
+    d, f = mk(False), mk(True)
+    d.reset(seed=7)
+    f.reset(seed=7)
+    act = np.concatenate([np.full((N, 1), 500.0), np.full((N, K), 0.7)], axis=1).astype(np.float32)
+    od, *_ = d.step(act)
+    of, *_ = f.step(act)
+    assert of.shape == (N, 5 * K + 2) and of.dtype == np.float32
+    for i in range(N):
+        assert np.array_equal(of[i], utils.flatten_dict_array({k: v[i] for k, v in od.items()}).astype(np.float32))
+    r = RLlibVectorEnvAdapter(f)
+    obs_list, infos = r.vector_reset(seeds=[7] * N)
+    o2, rew, term, trunc, infos = r.vector_step([a for a in act])
+    assert len(o2) == N and np.array_equal(np.stack(o2), of) and len(rew) == N
+    s = SB3VecEnvAdapter(mk(True))
+    s.seed(7)
+    o3 = s.reset()
+    o3, rew3, dones, infos3 = s.step(act)
+    assert np.array_equal(o3, of)
+    o3, rew3, dones, infos3 = s.step(act)
+    assert dones.all() and "terminal_observation" in infos3[0] and (o3 == 0).all()
+    for x in (d, f):
+        x.close()
+    s.close()
+
+
+def test_vectorised_sampler_for_large_env_counts(pkg):
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    vec = BiddingSimulationVectorEnv(2048, keyword_config=_cfg(16, 0.1, no_vol_prob=0.5), num_keywords=128,
+                                     param_sampler="vectorised")
+    vec.reset(seed=1)
+    obs, rew, term, trunc, _ = vec.step({"keyword_bids": np.full((2048, 128), 0.8, np.float32)})
+    assert obs["impressions"].shape == (2048, 128) and rew.shape == (2048,)
+    frac_zero = (obs["impressions"] == 0).mean()
+    assert 0.45 < frac_zero < 0.75          # half the keywords have no volume (no_vol_prob = 0.5)
+    vec.close()

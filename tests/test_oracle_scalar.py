@@ -126,7 +126,7 @@ def test_laplace_cents_law_matches_reference_sampler():
     hi = int(max(mine.max(), ref.max())) + 1
     a, b = np.bincount(mine, minlength=hi), np.bincount(ref, minlength=hi)
     keep = (a + b) >= 20
-    chi2 = (((a - b) ** 2) / (a + b))[keep].sum()
+    chi2 = (((a - b)[keep] ** 2) / (a + b)[keep]).sum()
     dof = keep.sum() - 1
     assert stats.chi2.sf(chi2, dof) > 1e-4
     assert abs(mine.mean() - ref.mean()) < 0.2
