@@ -93,7 +93,8 @@ def lib():
         "adc_engine_metrics_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_metrics_reset": ([vp], C.c_int),
         "adc_engine_metrics_read": ([vp, vp, vp], C.c_int),
-        "adc_engine_ideal_profit": ([vp, C.c_int, vp], C.c_int),
+        "adc_engine_ideal_profit": ([vp, C.c_int, vp, C.c_int, vp], C.c_int),
+        "adc_bid_curves_from_samples": ([C.c_int, vp, i32, vp, i32, vp, vp], C.c_int),
         "adc_nth_price_auction": ([C.c_int, f64, vp, i32, i32, i32, i32, C.POINTER(i32), vp, vp], C.c_int),
         "adc_sigmoid": ([f64, f64, f64], f64),
         "adc_clamp": ([f64, f64, f64], f64),

@@ -99,6 +99,7 @@ struct View {
     int64_t *metric_profit;      // [K]
     int64_t *metric_scalars;     // [8] (filled on read)
     int64_t *metric_env;         // [4][N] per-env running sums: profit cents, env steps, episodes, truncations
+    int64_t *metric_kw;          // [N][K] running sum of keyword profit, cents (metric mode)
 };
 
 __device__ __forceinline__ float &param_at(const View &v, int p, int env, int k)
@@ -718,6 +719,103 @@ __global__ void k_metric_reduce(View v)
     }
 }
 
+// metric mode: keyword profit of the step just finished -> running sums.  Outputs are float32 dollars;
+// cents are recovered exactly for |x| < 2^22 cents (the division by 100 was one correctly rounded op).
+__global__ void k_metric_accumulate(View v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nk = (size_t)v.N * v.K;
+    if (i >= nk) return;
+    const long long r = (long long)__builtin_rintf(v.rev[i] * 100.0f);
+    const long long c = v.model == ADC_MODEL_IMPLICIT ? (long long)__builtin_rintf(v.cost[i] * 100.0f)
+                                                      : (long long)__double2ll_rn((double)v.cost[i] * 100.0);
+    v.metric_kw[i] += r - c;
+}
+
+// metric_profit[k] = sum over envs of metric_kw[env][k]; one block per 256 keywords, 256 threads, env-strided
+__global__ void k_metric_columns(View v)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= v.K) return;
+    long long s = 0;
+    for (int e = 0; e < v.N; ++e) s += v.metric_kw[(size_t)e * v.K + k];
+    v.metric_profit[k] = s;
+}
+
+// ---- ideal (max expected) profit of a keyword, adcraft/experiment_utils/experiment_metrics.py:20-61 ------------
+// One wavefront per keyword.  n_samples competitor bids (cents) are histogrammed in LDS; for every bid b on
+// the grid 1..n_bids cents:  idx = #(samples <= b)  (searchsorted side="right", :30),  IR = idx / n (:32),
+// idx' = min(idx, n-1) (:33),  cpc = (sum of the idx'+1 smallest samples) / (idx'+1) (:34-35) - i.e. the mean
+// of the samples <= b PLUS the next larger one (the reference's off-by-one, reproduced) - and
+// profit(b) = max(vol_mean * IR * bctr * (sctr * rev_mean - cpc), 0) (:51-57); ideal = max_b (:59).
+constexpr int kIdealBins = 1024;      // cents 0..1022, last bin = everything above
+__global__ __launch_bounds__(kWave) void k_ideal_profit(View v, int n_samples, int n_bids, const double *__restrict__ bid_grid,
+                                                         const int32_t *tape_samples, double *ideal_out, double *ir_out, double *cpc_out)
+{
+    __shared__ unsigned int hist[kIdealBins];
+    __shared__ unsigned long long over_sum;
+    __shared__ unsigned int over_min;
+    const int lane = threadIdx.x;
+    const int env = blockIdx.x / v.K, k = blockIdx.x - env * v.K;
+    for (int i = lane; i < kIdealBins; i += kWave) hist[i] = 0u;
+    if (lane == 0) { over_sum = 0ull; over_min = 0xFFFFFFFFu; }
+    __syncthreads();
+    const float loc = param_at(v, ADC_P_A, env, k), scale = param_at(v, ADC_P_B, env, k);
+    const uint64_t key = v.key[env];
+    const uint32_t tick = v.tick[env];
+    for (int i = lane; i < n_samples; i += kWave) {
+        int c;
+        if (tape_samples) c = tape_samples[(size_t)blockIdx.x * n_samples + i];
+        else {
+            const adc::U4 w = adc::draw(key, (uint32_t)(i >> 2), adc::ST_METRIC, (uint32_t)k, tick);
+            const uint32_t ws = (i & 3) == 0 ? w.x : (i & 3) == 1 ? w.y : (i & 3) == 2 ? w.z : w.w;
+            c = adc::laplace_cents(ws, loc, scale);
+        }
+        if (c < kIdealBins - 1) atomicAdd(&hist[c], 1u);
+        else {
+            atomicAdd(&hist[kIdealBins - 1], 1u);
+            atomicAdd(&over_sum, (unsigned long long)c);
+            atomicMin(&over_min, (unsigned int)c);
+        }
+    }
+    __syncthreads();
+    const double vol_mean = param_at(v, ADC_P_VOL_MEAN, env, k), bctr = param_at(v, ADC_P_BCTR, env, k);
+    const double margin = (double)param_at(v, ADC_P_SCTR, env, k) * (double)param_at(v, ADC_P_REV_MEAN, env, k);
+    // serial scan by lane 0 over the bid grid (n_bids <= 1022); the histogram prefix is carried along
+    if (lane == 0) {
+        unsigned long long cnt = 0, sum = 0;    // over samples with dollars <= bid
+        double best = 0.0;
+        int bin = 0;
+        for (int bi = 1; bi <= n_bids; ++bi) {
+            // the reference compares float dollars: sample c/100.0 <= bid, with bid from np.arange (so e.g. its
+            // "0.10" is 0.09999999999999999 and excludes 10-cent samples).  b = largest cent value that passes.
+            const double bid = bid_grid[bi - 1];
+            int b = (int)__builtin_floor(bid * 100.0 + 0.5);
+            if (b > kIdealBins - 2) b = kIdealBins - 2;
+            if (b >= 0 && !((double)b / 100.0 <= bid)) b -= 1;
+            for (; bin <= b && bin < kIdealBins - 1; ++bin) { cnt += hist[bin]; sum += (unsigned long long)hist[bin] * bin; }
+            const unsigned long long idx = cnt;
+            const double ir = (double)idx / (double)n_samples;
+            double num = (double)sum / 100.0, den;
+            if (idx >= (unsigned long long)n_samples) den = (double)n_samples;       // idx' = n-1: all samples
+            else {
+                // add the smallest sample above b (sorted[idx]); then idx'+1 = idx+1 terms
+                int nb = bin;                       // first bin not yet counted
+                while (nb < kIdealBins - 1 && hist[nb] == 0u) ++nb;
+                num = ((double)sum + (nb < kIdealBins - 1 ? (double)nb : (double)over_min)) / 100.0;
+                den = (double)(idx + 1);
+            }
+            const double cpc = num / den;
+            if (ir_out) ir_out[(size_t)blockIdx.x * n_bids + (bi - 1)] = ir;
+            if (cpc_out) cpc_out[(size_t)blockIdx.x * n_bids + (bi - 1)] = cpc;
+            double p = vol_mean * ir * bctr * (margin - cpc);
+            p = p > 0.0 ? p : 0.0;
+            best = p > best ? p : best;
+        }
+        if (ideal_out) ideal_out[blockIdx.x] = best;
+    }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;
@@ -883,6 +981,11 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
         hipLaunchKernelGGL((k_step_exact<ADC_MODEL_EXPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 0);
     }
     HIP_TRY(hipGetLastError());
+    if (v.metrics_on) {
+        const size_t nk = (size_t)N * K;
+        hipLaunchKernelGGL(k_metric_accumulate, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, e->stream, v);
+        HIP_TRY(hipGetLastError());
+    }
     return ADC_OK;
 }
 
@@ -970,7 +1073,7 @@ ADC_EXPORT int adc_engine_create(const adc_config *cfg, adc_engine **out)
     A(v.env_cost, N); A(v.env_profit, N);
     A(v.imp, NK); A(v.clk, NK); A(v.conv, NK); A(v.cost, NK); A(v.rev, NK);
     A(v.reward, N); A(v.cum_profit, N); A(v.day_out, N); A(v.term, N); A(v.trunc, N);
-    A(v.metric_profit, K); A(v.metric_scalars, 8); A(v.metric_env, 4 * N);
+    A(v.metric_profit, K); A(v.metric_scalars, 8); A(v.metric_env, 4 * N); A(v.metric_kw, NK);
     A(e->d_bids, NK); A(e->d_budget, N);
 #undef A
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, v, cfg->seed, cfg->env_id_base);
@@ -1315,12 +1418,17 @@ ADC_EXPORT int adc_engine_metrics_reset(adc_engine *e)
     HIP_TRY(hipMemsetAsync(e->v.metric_profit, 0, (size_t)e->v.K * 8, e->stream));
     HIP_TRY(hipMemsetAsync(e->v.metric_scalars, 0, 64, e->stream));
     HIP_TRY(hipMemsetAsync(e->v.metric_env, 0, (size_t)e->v.N * 32, e->stream));
+    HIP_TRY(hipMemsetAsync(e->v.metric_kw, 0, (size_t)e->v.N * e->v.K * 8, e->stream));
     return ADC_OK;
 }
 
 ADC_EXPORT int adc_engine_metrics_read(adc_engine *e, int64_t *keyword_profit_cents_k, int64_t *scalars8)
 {
     ENGINE_GUARD(e);
+    if (keyword_profit_cents_k) {
+        hipLaunchKernelGGL(k_metric_columns, dim3((unsigned)((e->v.K + 255) / 256)), dim3(256), 0, e->stream, e->v);
+        HIP_TRY(hipGetLastError());
+    }
     if (keyword_profit_cents_k) HIP_TRY(hipMemcpyAsync(keyword_profit_cents_k, e->v.metric_profit, (size_t)e->v.K * 8, hipMemcpyDeviceToHost, e->stream));
     if (scalars8) {
         hipLaunchKernelGGL(k_metric_reduce, dim3(4), dim3(256), 0, e->stream, e->v);
@@ -1331,11 +1439,62 @@ ADC_EXPORT int adc_engine_metrics_read(adc_engine *e, int64_t *keyword_profit_ce
     return ADC_OK;
 }
 
-ADC_EXPORT int adc_engine_ideal_profit(adc_engine *e, int n_samples, double *host_nk)
+ADC_EXPORT int adc_engine_ideal_profit(adc_engine *e, int n_samples, const double *bid_grid, int n_bids, double *host_nk)
 {
     ENGINE_GUARD(e);
-    (void)n_samples; (void)host_nk;
-    return fail(ADC_ESTATE, "adc_engine_ideal_profit: not built yet in this round");
+    if (e->v.model != ADC_MODEL_IMPLICIT) return fail(ADC_EINVAL, "ideal profit is defined for IMPLICIT keywords");
+    if (n_samples <= 0 || !host_nk || !bid_grid || n_bids <= 0) return fail(ADC_EINVAL, "bad arguments");
+    const size_t nk = (size_t)e->v.N * e->v.K;
+    if (e->v.drift_on) { hipLaunchKernelGGL(k_materialize_drift, dim3(e->v.N), dim3(256), 0, e->stream, e->v); HIP_TRY(hipGetLastError()); }
+    double *d_out = nullptr, *d_grid = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, nk * 8));
+    hipError_t err = hipMalloc((void **)&d_grid, (size_t)n_bids * 8);
+    if (err == hipSuccess) err = hipMemcpyAsync(d_grid, bid_grid, (size_t)n_bids * 8, hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(k_ideal_profit, dim3((unsigned)nk), dim3(kWave), 0, e->stream, e->v, n_samples, n_bids, d_grid,
+                           (const int32_t *)nullptr, d_out, (double *)nullptr, (double *)nullptr);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(host_nk, d_out, nk * 8, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_out);
+    (void)hipFree(d_grid);
+    HIP_TRY(err);
+    return ADC_OK;
+}
+
+// the estimator alone, on caller-supplied samples of ONE keyword (pins the kernel against the reference's
+// get_implicit_kw_bid_cpc_impressions; bid grid = 1..n_bids cents)
+ADC_EXPORT int adc_bid_curves_from_samples(int device_id, const int32_t *samples_cents, int32_t n_samples, const double *bid_grid,
+                                           int32_t n_bids, double *impression_rate_out, double *cpc_out)
+{
+    if (!samples_cents || n_samples <= 0 || n_bids <= 0 || !bid_grid || !impression_rate_out || !cpc_out)
+        return fail(ADC_EINVAL, "bad arguments");
+    HIP_TRY(hipSetDevice(device_id));
+    int32_t *d_s = nullptr;
+    double *d_ir = nullptr, *d_cpc = nullptr, *d_grid = nullptr;
+    float *d_p = nullptr;
+    uint64_t *d_key = nullptr;
+    uint32_t *d_tick = nullptr;
+    auto done = [&](int code) { (void)hipFree(d_s); (void)hipFree(d_ir); (void)hipFree(d_cpc); (void)hipFree(d_p); (void)hipFree(d_key); (void)hipFree(d_tick); (void)hipFree(d_grid); return code; };
+    if (hipMalloc((void **)&d_s, (size_t)n_samples * 4) != hipSuccess || hipMalloc((void **)&d_ir, (size_t)n_bids * 8) != hipSuccess ||
+        hipMalloc((void **)&d_cpc, (size_t)n_bids * 8) != hipSuccess || hipMalloc((void **)&d_p, ADC_P_COUNT * 4) != hipSuccess ||
+        hipMalloc((void **)&d_key, 8) != hipSuccess || hipMalloc((void **)&d_tick, 4) != hipSuccess ||
+        hipMalloc((void **)&d_grid, (size_t)n_bids * 8) != hipSuccess)
+        return done(fail(ADC_ENOMEM, "hipMalloc failed"));
+    if (hipMemcpy(d_grid, bid_grid, (size_t)n_bids * 8, hipMemcpyHostToDevice) != hipSuccess) return done(fail(ADC_EHIP, "upload failed"));
+    if (hipMemcpy(d_s, samples_cents, (size_t)n_samples * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_p, 0, ADC_P_COUNT * 4) != hipSuccess ||
+        hipMemset(d_key, 0, 8) != hipSuccess || hipMemset(d_tick, 0, 4) != hipSuccess)
+        return done(fail(ADC_EHIP, "upload failed"));
+    View v;
+    std::memset(&v, 0, sizeof(v));
+    v.N = 1; v.K = 1; v.params = d_p; v.key = d_key; v.tick = d_tick;
+    hipLaunchKernelGGL(k_ideal_profit, dim3(1), dim3(kWave), 0, 0, v, n_samples, n_bids, d_grid, d_s, (double *)nullptr, d_ir, d_cpc);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail(ADC_EHIP, "k_ideal_profit failed"));
+    if (hipMemcpy(impression_rate_out, d_ir, (size_t)n_bids * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(cpc_out, d_cpc, (size_t)n_bids * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(ADC_EHIP, "download failed"));
+    return done(ADC_OK);
 }
 
 ADC_EXPORT int adc_nth_price_auction(int device_id, double bid, const double *other_bids, int32_t n_auctions, int32_t n_bidders,

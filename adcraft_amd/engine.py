@@ -171,6 +171,14 @@ class StepEngine:
     def metrics_reset(self):
         check(self._lib.adc_engine_metrics_reset(self._h))
 
+    def ideal_profit(self, n_samples=2048, bid_grid=None):
+        """max expected profit per keyword from the current parameters (experiment_metrics.py:20-61), dollars [N, K];
+        bid_grid defaults to the notebooks' np.arange(0.01, 3.00, 0.01)"""
+        grid = np.ascontiguousarray(np.arange(0.01, 3.00, 0.01) if bid_grid is None else bid_grid, dtype=np.float64)
+        out = np.zeros((self.num_envs, self.num_keywords), dtype=np.float64)
+        check(self._lib.adc_engine_ideal_profit(self._h, int(n_samples), grid.ctypes.data, grid.size, out.ctypes.data))
+        return out
+
     def metrics_read(self):
         kp = np.zeros(self.num_keywords, dtype=np.int64)
         sc = np.zeros(8, dtype=np.int64)

@@ -110,7 +110,7 @@ typedef enum adc_buffer {
     ADC_BUF_DAYS = 10,         /* int32 [N] */
     ADC_BUF_TERMINATED = 11,   /* uint8 [N] */
     ADC_BUF_TRUNCATED = 12,
-    ADC_BUF_METRIC_PROFIT = 13,/* int64 [K]  sum over local envs and steps of keyword profit, cents (IMPLICIT) */
+    ADC_BUF_METRIC_PROFIT = 13,/* int64 [K]  sum over local envs and steps of keyword profit, cents (valid after metrics_read) */
     ADC_BUF_METRIC_SCALARS = 14,/* int64 [8]  {profit_cents, env_steps, episodes, truncations, auctions, 0,0,0} */
     ADC_BUF_FLAT_OBS = 15      /* float [N][5K+2] FlatArrayWrapper layout (adcraft/wrappers/flat_array.py:74-80) */
 } adc_buffer;
@@ -199,9 +199,15 @@ int adc_engine_metrics_enable(adc_engine *e, int enabled);
 int adc_engine_metrics_reset(adc_engine *e);
 /* local (this device) accumulators to host: keyword_profit_cents [K], scalars [8] */
 int adc_engine_metrics_read(adc_engine *e, int64_t *keyword_profit_cents_k, int64_t *scalars8);
-/* ideal (max expected) profit per keyword from the CURRENT parameters, 2048 sampled competitor bids and
- * the bid grid 0.01..2.99 (experiment_metrics.py:20-61); host double [N*K] */
-int adc_engine_ideal_profit(adc_engine *e, int n_samples, double *host_nk);
+/* ideal (max expected) profit per keyword from the CURRENT parameters, n_samples sampled competitor bids and an
+ * ascending bid grid in dollars (the notebooks use np.arange(0.01, 3.00, 0.01)); experiment_metrics.py:20-61;
+ * host double [N*K] */
+int adc_engine_ideal_profit(adc_engine *e, int n_samples, const double *bid_grid, int n_bids, double *host_nk);
+/* the estimator alone, on caller-supplied competitor-bid samples (cents) of one keyword: impression rate and
+ * expected cpc on the given bid grid, exactly as get_implicit_kw_bid_cpc_impressions computes them
+ * (experiment_metrics.py:28-37, including its inclusive running-mean index) */
+int adc_bid_curves_from_samples(int device_id, const int32_t *samples_cents, int32_t n_samples, const double *bid_grid,
+                                int32_t n_bids, double *impression_rate_out, double *cpc_out);
 
 /* ---- standalone auction clearing (adcraft/synthetic_kw_helpers.py:116-180) ------------------------ */
 /* other_bids: host double [n_auctions][n_bidders]; placements/costs: host, capacity n_auctions.

@@ -297,3 +297,66 @@ def test_full_size_cfg2_properties(amd):
     assert np.array_equal(a["buyside_clicks"][sub], ref["clicks"])
     assert np.array_equal(a["reward"][sub], ref["reward"])
     e.close()
+
+
+# ------------------------------------------------------------------ metrics on the device
+def test_bid_curves_estimator_matches_reference(amd, golden):
+    """k_ideal_profit's estimator on the reference's own samples == get_implicit_kw_bid_cpc_impressions (G5)"""
+    from adcraft_amd import _ffi
+    g = golden("g5_metrics.json")
+    L = _ffi.lib()
+    for c in g["bid_curves"]:
+        s = np.array(c["samples_cents"], dtype=np.int32)
+        ir = np.zeros(299)
+        cpc = np.zeros(299)
+        grid = np.array(g["bid_array"], dtype=np.float64)
+        assert grid.size == 299
+        _ffi.check(L.adc_bid_curves_from_samples(0, s.ctypes.data, s.size, grid.ctypes.data, 299, ir.ctypes.data, cpc.ctypes.data))
+        assert ir.tolist() == c["impression_rates"]
+        np.testing.assert_allclose(cpc, c["cpc"], rtol=1e-12)
+
+
+def test_ideal_profit_matches_host_restatement(amd):
+    from oracle import capi as orc, ref_numpy as rn
+    N, K, n = 2, 6, 2048
+    planes = H.implicit_params(N, K, seed=31)
+    e = amd.StepEngine(N, K, seed=5)
+    e.set_all_params(planes)
+    e.reset()
+    got = e.ideal_profit(n)
+    keys, ticks = e.get_rng_state()
+    bids = np.arange(0.01, 3.00, 0.01)
+    L = orc.lib()
+    for env in range(N):
+        for k in range(K):
+            cents = []
+            for i in range(n // 4):
+                w = orc.philox([i, 6, k, int(ticks[env])], [int(keys[env]) & 0xFFFFFFFF, int(keys[env]) >> 32])
+                cents += [L.orc_laplace_cents_from_word(int(x), float(planes[2, env, k]), float(planes[3, env, k])) for x in w]
+            ir, cpc = rn.implicit_bid_cpc_impressions(np.array(cents, dtype=np.float64).reshape(1, -1) / 100.0, bids)
+            kwp = [[float(planes[0, env, k]), 0.0], 0, 0, float(planes[4, env, k]), float(planes[5, env, k]), float(planes[6, env, k])]
+            ref = rn.max_expected_bid_profits(kwp, cpc, ir)[0]
+            assert got[env, k] == pytest.approx(ref, rel=1e-9, abs=1e-12)
+    e.close()
+
+
+def test_metric_accumulators(amd):
+    N, K = 5, 70
+    planes = H.implicit_params(N, K, seed=32)
+    e = amd.StepEngine(N, K, seed=6, max_days=3, auto_reset=True)
+    e.set_all_params(planes)
+    e.reset()
+    e.metrics_enable(True)
+    e.metrics_reset()
+    prof = np.zeros(K, dtype=np.int64)
+    tot = 0
+    rng = np.random.default_rng(0)
+    for s in range(4):
+        budget = 1e9 if s % 2 == 0 else 30.0          # exercise both passes
+        out = e.step(rng.uniform(0.3, 1.0, (N, K)).astype(np.float32), budget)
+        cents = np.rint(out["revenue"].astype(np.float64) * 100) - np.rint(out["cost"].astype(np.float64) * 100)
+        prof += cents.sum(axis=0).astype(np.int64)
+        tot += int(np.rint(out["reward"] * 100).sum())
+    kp, sc = e.metrics_read()
+    assert np.array_equal(kp, prof) and sc[0] == tot and sc[1] == 4 * N and sc[2] == N and sc[3] == 0
+    e.close()
