@@ -85,14 +85,17 @@ def main():
     eng.sample_actions(0.30, 1.00, 1.0e9)        # actions resident in HBM before the timed region
     eng.metrics_enable(True)
 
-    def metric_allreduce():
+    from adcraft_amd import distributed as D, experiment_metrics as em
+    # stationary keywords: the ideal (max expected) profit per keyword is constant over the episode
+    ideal_k = eng.ideal_profit(2048).sum(axis=0) if not drift else eng.ideal_profit(2048).sum(axis=0)
+
+    def metric_allreduce(steps_done):
+        """the single collective of the path: [sum profit_k | sum ideal_k | scalars], RCCL over xGMI for N>1"""
         kp, sc = eng.metrics_read()
+        vec = D.pack_metric_vector(kp, ideal_k * steps_done, sc)
         if dist is not None:
-            import torch
-            t = torch.from_numpy(np.concatenate([kp, sc])).cuda()
-            dist.all_reduce(t)                   # the single RCCL collective of the path (episode metric)
-            return t.cpu().numpy()
-        return np.concatenate([kp, sc])
+            vec = D.all_reduce_sum(vec, device="cuda")
+        return vec
 
     def barrier():
         eng.synchronize()
@@ -112,12 +115,12 @@ def main():
     for s in range(args.steps):
         eng.step_device()
         if dist is not None and (s + 1) % max_days == 0:
-            metric_allreduce()
+            metric_allreduce(s + 1)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = eng.profile_read()
     eng.profile_enable(False)
-    totals = metric_allreduce()
+    totals = metric_allreduce(args.steps)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -155,8 +158,11 @@ def main():
                          "kernel": "k_step_implicit_fast", "kernel_ms": k_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": b_alg},
         }
-        sc = totals[K:]
-        line["episode_metric"] = {"profit_dollars": float(sc[0]) / 100.0, "env_steps": int(sc[1]), "episodes": int(sc[2])}
+        profit_c, ideal, sc = D.unpack_metric_vector(totals, K)
+        akncp, ncp = em.akncp_ncp_from_sums(profit_c / 100.0, ideal)
+        line["episode_metric"] = {"AKNCP": akncp, "NCP": ncp, "profit_dollars": float(sc[0]) / 100.0,
+                                  "env_steps": int(sc[1]), "episodes": int(sc[2]),
+                                  "note": "synthetic uniform bids, not a trained agent"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.config, planes, K, args.cpu_seconds)
         print(json.dumps(line), flush=True)
