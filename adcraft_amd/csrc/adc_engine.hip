@@ -732,14 +732,18 @@ __global__ void k_metric_accumulate(View v)
     v.metric_kw[i] += r - c;
 }
 
-// metric_profit[k] = sum over envs of metric_kw[env][k]; one block per 256 keywords, 256 threads, env-strided
+// metric_profit[k] += sum over a slab of envs of metric_kw[env][k]; grid = (K tiles, env slabs); metric_profit is
+// zeroed before the launch
+constexpr int kColumnSlabs = 64;
 __global__ void k_metric_columns(View v)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= v.K) return;
+    const int per = (v.N + kColumnSlabs - 1) / kColumnSlabs;
+    const int e0 = blockIdx.y * per, e1 = min(v.N, e0 + per);
     long long s = 0;
-    for (int e = 0; e < v.N; ++e) s += v.metric_kw[(size_t)e * v.K + k];
-    v.metric_profit[k] = s;
+    for (int e = e0; e < e1; ++e) s += v.metric_kw[(size_t)e * v.K + k];
+    if (e1 > e0) atomicAdd((unsigned long long *)&v.metric_profit[k], (unsigned long long)s);
 }
 
 // ---- ideal (max expected) profit of a keyword, adcraft/experiment_utils/experiment_metrics.py:20-61 ------------
@@ -752,13 +756,15 @@ constexpr int kIdealBins = 1024;      // cents 0..1022, last bin = everything ab
 __global__ __launch_bounds__(kWave) void k_ideal_profit(View v, int n_samples, int n_bids, const double *__restrict__ bid_grid,
                                                          const int32_t *tape_samples, double *ideal_out, double *ir_out, double *cpc_out)
 {
-    __shared__ unsigned int hist[kIdealBins];
-    __shared__ unsigned long long over_sum;
+    __shared__ unsigned int hist[kIdealBins];      // count per cent value (last bin: everything above)
+    __shared__ unsigned int cpre[kIdealBins];      // inclusive prefix of counts
+    __shared__ unsigned int spre[kIdealBins];      // inclusive prefix of cents (<= 2^21 * 1022 fits for n <= 2^21)
+    __shared__ unsigned int nxt[kIdealBins + 1];   // smallest occupied bin >= i (kIdealBins-1 stands for "above")
     __shared__ unsigned int over_min;
     const int lane = threadIdx.x;
     const int env = blockIdx.x / v.K, k = blockIdx.x - env * v.K;
     for (int i = lane; i < kIdealBins; i += kWave) hist[i] = 0u;
-    if (lane == 0) { over_sum = 0ull; over_min = 0xFFFFFFFFu; }
+    if (lane == 0) over_min = 0xFFFFFFFFu;
     __syncthreads();
     const float loc = param_at(v, ADC_P_A, env, k), scale = param_at(v, ADC_P_B, env, k);
     const uint64_t key = v.key[env];
@@ -774,46 +780,83 @@ __global__ __launch_bounds__(kWave) void k_ideal_profit(View v, int n_samples, i
         if (c < kIdealBins - 1) atomicAdd(&hist[c], 1u);
         else {
             atomicAdd(&hist[kIdealBins - 1], 1u);
-            atomicAdd(&over_sum, (unsigned long long)c);
             atomicMin(&over_min, (unsigned int)c);
         }
     }
     __syncthreads();
+    // prefix sums over bins: each lane owns 16 consecutive bins, wave scan joins them
+    constexpr int kPer = kIdealBins / kWave;
+    unsigned int lc = 0, ls = 0;
+    for (int i = 0; i < kPer; ++i) {
+        const int bin = lane * kPer + i;
+        const unsigned int h = bin < kIdealBins - 1 ? hist[bin] : 0u;
+        lc += h;
+        ls += h * (unsigned int)bin;
+    }
+    const unsigned int bc = (unsigned int)wave_scan_i32((int)lc) - lc, bs = (unsigned int)wave_scan_i32((int)ls) - ls;
+    lc = bc; ls = bs;
+    for (int i = 0; i < kPer; ++i) {
+        const int bin = lane * kPer + i;
+        const unsigned int h = bin < kIdealBins - 1 ? hist[bin] : 0u;
+        lc += h;
+        ls += h * (unsigned int)bin;
+        cpre[bin] = lc;
+        spre[bin] = ls;
+    }
+    // smallest occupied bin at or after i: backward over the lane's bins, then across lanes
+    unsigned int first = 0xFFFFFFFFu;
+    for (int i = kPer - 1; i >= 0; --i) {
+        const int bin = lane * kPer + i;
+        if (hist[bin] != 0u) first = (unsigned int)bin;
+    }
+    unsigned int after = 0xFFFFFFFFu;          // first occupied bin in any later lane
+    for (int l = kWave - 1; l > 0; --l) {
+        const unsigned int f = (unsigned int)__shfl((int)first, l, 64);
+        if (lane < l && f < after) after = f;          // evaluated high to low, so "after" ends as the nearest
+    }
+    {
+        unsigned int run = after;
+        for (int i = kPer - 1; i >= 0; --i) {
+            const int bin = lane * kPer + i;
+            if (hist[bin] != 0u) run = (unsigned int)bin;
+            nxt[bin] = run == 0xFFFFFFFFu ? (unsigned int)(kIdealBins - 1) : run;
+        }
+    }
+    if (lane == 0) nxt[kIdealBins] = kIdealBins - 1;
+    __syncthreads();
     const double vol_mean = param_at(v, ADC_P_VOL_MEAN, env, k), bctr = param_at(v, ADC_P_BCTR, env, k);
     const double margin = (double)param_at(v, ADC_P_SCTR, env, k) * (double)param_at(v, ADC_P_REV_MEAN, env, k);
-    // serial scan by lane 0 over the bid grid (n_bids <= 1022); the histogram prefix is carried along
-    if (lane == 0) {
-        unsigned long long cnt = 0, sum = 0;    // over samples with dollars <= bid
-        double best = 0.0;
-        int bin = 0;
-        for (int bi = 1; bi <= n_bids; ++bi) {
-            // the reference compares float dollars: sample c/100.0 <= bid, with bid from np.arange (so e.g. its
-            // "0.10" is 0.09999999999999999 and excludes 10-cent samples).  b = largest cent value that passes.
-            const double bid = bid_grid[bi - 1];
-            int b = (int)__builtin_floor(bid * 100.0 + 0.5);
-            if (b > kIdealBins - 2) b = kIdealBins - 2;
-            if (b >= 0 && !((double)b / 100.0 <= bid)) b -= 1;
-            for (; bin <= b && bin < kIdealBins - 1; ++bin) { cnt += hist[bin]; sum += (unsigned long long)hist[bin] * bin; }
-            const unsigned long long idx = cnt;
-            const double ir = (double)idx / (double)n_samples;
-            double num = (double)sum / 100.0, den;
-            if (idx >= (unsigned long long)n_samples) den = (double)n_samples;       // idx' = n-1: all samples
-            else {
-                // add the smallest sample above b (sorted[idx]); then idx'+1 = idx+1 terms
-                int nb = bin;                       // first bin not yet counted
-                while (nb < kIdealBins - 1 && hist[nb] == 0u) ++nb;
-                num = ((double)sum + (nb < kIdealBins - 1 ? (double)nb : (double)over_min)) / 100.0;
-                den = (double)(idx + 1);
-            }
-            const double cpc = num / den;
-            if (ir_out) ir_out[(size_t)blockIdx.x * n_bids + (bi - 1)] = ir;
-            if (cpc_out) cpc_out[(size_t)blockIdx.x * n_bids + (bi - 1)] = cpc;
-            double p = vol_mean * ir * bctr * (margin - cpc);
-            p = p > 0.0 ? p : 0.0;
-            best = p > best ? p : best;
+    double best = 0.0;
+    for (int bi = lane; bi < n_bids; bi += kWave) {
+        // the reference compares float dollars: sample c/100.0 <= bid, with bid from np.arange (so e.g. its
+        // "0.10" is 0.09999999999999999 and excludes 10-cent samples).  b = largest cent value that passes.
+        const double bid = bid_grid[bi];
+        int b = (int)__builtin_floor(bid * 100.0 + 0.5);
+        if (b > kIdealBins - 2) b = kIdealBins - 2;
+        if (b >= 0 && !((double)b / 100.0 <= bid)) b -= 1;
+        const unsigned long long idx = b >= 0 ? cpre[b] : 0u;          // searchsorted side="right" (:30)
+        const unsigned long long sum = b >= 0 ? spre[b] : 0u;
+        const double ir = (double)idx / (double)n_samples;             // :32
+        double num, den;
+        if (idx >= (unsigned long long)n_samples) { num = (double)sum / 100.0; den = (double)n_samples; }   // idx' = n-1
+        else {
+            const unsigned int nb = nxt[b + 1];                         // sorted[idx]: the smallest sample above the bid
+            num = ((double)sum + (nb < (unsigned int)(kIdealBins - 1) ? (double)nb : (double)over_min)) / 100.0;
+            den = (double)(idx + 1);                                    // :33-35 inclusive running mean
         }
-        if (ideal_out) ideal_out[blockIdx.x] = best;
+        const double cpc = num / den;
+        if (ir_out) ir_out[(size_t)blockIdx.x * n_bids + bi] = ir;
+        if (cpc_out) cpc_out[(size_t)blockIdx.x * n_bids + bi] = cpc;
+        double p = vol_mean * ir * bctr * (margin - cpc);               // :51-57
+        p = p > 0.0 ? p : 0.0;
+        best = p > best ? p : best;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if (lane == 0 && ideal_out) ideal_out[blockIdx.x] = best;           // :59
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -1426,7 +1469,8 @@ ADC_EXPORT int adc_engine_metrics_read(adc_engine *e, int64_t *keyword_profit_ce
 {
     ENGINE_GUARD(e);
     if (keyword_profit_cents_k) {
-        hipLaunchKernelGGL(k_metric_columns, dim3((unsigned)((e->v.K + 255) / 256)), dim3(256), 0, e->stream, e->v);
+        HIP_TRY(hipMemsetAsync(e->v.metric_profit, 0, (size_t)e->v.K * 8, e->stream));
+        hipLaunchKernelGGL(k_metric_columns, dim3((unsigned)((e->v.K + 255) / 256), kColumnSlabs), dim3(256), 0, e->stream, e->v);
         HIP_TRY(hipGetLastError());
     }
     if (keyword_profit_cents_k) HIP_TRY(hipMemcpyAsync(keyword_profit_cents_k, e->v.metric_profit, (size_t)e->v.K * 8, hipMemcpyDeviceToHost, e->stream));
