@@ -334,6 +334,46 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
     }
 }
 
+// step tail (gymnasium_kw_env.py:222-244), run by one lane per env
+__device__ __forceinline__ void step_tail(const View &v, int env, uint32_t tick, bool implicit, long long profit_c, double reward_d)
+{
+    double reward, cum;
+    if (implicit) {
+        const long long cc = v.cum_cents[env] + profit_c;
+        v.cum_cents[env] = cc;
+        reward = (double)profit_c / 100.0;
+        cum = (double)cc / 100.0;
+    } else {
+        reward = reward_d;
+        cum = v.cum[env] + reward;
+        v.cum[env] = cum;
+    }
+    const bool truncated = cum < -v.loss_threshold;                 // :225
+    const int day = v.day[env] + 1;                                  // :227
+    const bool terminated = day >= v.max_days;                       // :228
+    v.reward[env] = reward;
+    v.cum_profit[env] = cum;
+    v.day_out[env] = day;
+    v.term[env] = terminated;
+    v.trunc[env] = truncated;
+    v.day[env] = day;
+    v.tick[env] = tick + 1u;
+    if (v.drift_on) v.drift_pending[env] = 1;                        // :246 update_keywords()
+    if (v.auto_reset && (terminated || truncated)) {
+        v.day[env] = 0; v.cum_cents[env] = 0; v.cum[env] = 0.0;      // :327-328
+    }
+    v.env_cost[env] = 0;
+    v.env_profit[env] = 0;
+    if (v.metrics_on) {
+        // per-env running sums (no same-address atomics: 4096 waves on one word serialise at ~12 ns each)
+        const long long pc = implicit ? profit_c : (long long)__double2ll_rn(reward * 100.0);
+        v.metric_env[env] += pc;
+        v.metric_env[(size_t)v.N + env] += 1;
+        if (terminated || truncated) v.metric_env[2 * (size_t)v.N + env] += 1;
+        if (truncated) v.metric_env[3 * (size_t)v.N + env] += 1;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // EXACT PASS + STEP TAIL: one wavefront per env
 // -------------------------------------------------------------------------------------------------
@@ -625,43 +665,286 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
         profit_c = v.env_profit[env];
     }
 
-    // ---- step tail (gymnasium_kw_env.py:222-244) ---------------------------------------------------
-    if (lane == 0) {
-        double reward, cum;
-        if (MODEL == ADC_MODEL_IMPLICIT) {
-            const long long cc = v.cum_cents[env] + profit_c;
-            v.cum_cents[env] = cc;
-            reward = (double)profit_c / 100.0;
-            cum = (double)cc / 100.0;
+    if (lane == 0) step_tail(v, env, tick, MODEL == ADC_MODEL_IMPLICIT, profit_c, reward_d);
+}
+
+// -------------------------------------------------------------------------------------------------
+// EXACT PASS, ROW-PARALLEL (IMPLICIT, engine stream): one 256-lane workgroup per env
+// -------------------------------------------------------------------------------------------------
+// The reference walks the day's 24 x K cells in order (t-major, keyword-minor) with one shared budget
+// (adcraft/bidding_simulation.py:214-233).  Per sub-timestep row t:
+//   pass A  every cell (t,k) of the row is evaluated in parallel (one lane per cell): wins W, clicked
+//           wins NC, their total cost T, and the cost X1 of the first clicked win;
+//   resolve the budget walk over the row's cells, in keyword order, as a loop of three block-wide steps:
+//           (a) bulk - cells whose running total stays strictly below the remaining budget are paid in
+//               full (every click affordable, remaining stays > 0);
+//           (b) the first cell that does not fit is walked click by click by its lane (pay while the
+//               running cost fits, :97-104); exact exhaustion (remaining == 0) stops the campaign (:230-233);
+//           (c) skip - with what is left, a cell whose FIRST click is unaffordable pays nothing (the
+//               reference breaks at it), so jump to the next cell with X1 <= remaining;
+//   pass B  cells paid in full are re-walked with the conversion / revenue draws; the others only count
+//           their impressions (impressions are not budget-limited, :86-88).
+// Costs are >= 0, so remaining never increases and (a)/(c) are exact, not heuristics.
+constexpr int kRowsBlock = 256;
+constexpr int kRowsMaxK = 1024;
+
+struct CellStat {
+    unsigned int wins, clicks, first;     // first = cost of the first clicked win (0xFFFFFFFF if none)
+    unsigned long long total;             // cost of all clicked wins
+};
+
+// mode 0: statistics only.  mode 1: every click is paid (adds conversions / revenue).  mode 2: pay while the
+// running cost fits `budget` (the reference's in-cell loop); `paid_cost` returns what was spent.
+template <int MODE>
+__device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint32_t kw, int j0, int n, int bid_c, float loc,
+                                              float scale, unsigned long long t_click, unsigned long long t_conv, float mu,
+                                              float sd, long long budget, unsigned int &conv_out,
+                                              unsigned long long &rev_out, unsigned long long &paid_cost)
+{
+    CellStat st{0u, 0u, 0xFFFFFFFFu, 0ull};
+    conv_out = 0u;
+    rev_out = 0ull;
+    paid_cost = 0ull;
+    bool broke = false;
+    const int jend = j0 + n;
+    for (int p = j0 >> 1; 2 * p < jend; ++p) {
+        const adc::U4 w = adc::draw(key, (uint32_t)p, adc::ST_AUCTION, kw, tick);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 2 * p + h;
+            if (j < j0 || j >= jend) continue;
+            const int comp = adc::laplace_cents(h ? w.z : w.x, loc, scale);
+            if (!(bid_c > comp)) continue;
+            st.wins += 1u;
+            if (!adc::bernoulli(h ? w.w : w.y, t_click)) continue;
+            if (MODE == 0) {
+                st.clicks += 1u;
+                st.total += (unsigned long long)comp;
+                if (st.first == 0xFFFFFFFFu) st.first = (unsigned int)comp;
+                continue;
+            }
+            if (MODE == 2) {
+                if (broke) continue;
+                if ((long long)(paid_cost + (unsigned long long)comp) > budget) { broke = true; continue; }
+            }
+            st.clicks += 1u;
+            paid_cost += (unsigned long long)comp;
+            const adc::U4 w2 = adc::draw(key, (uint32_t)j, adc::ST_CONV, kw, tick);
+            if (adc::bernoulli(w2.x, t_conv)) {
+                conv_out += 1u;
+                rev_out += (unsigned long long)adc::revenue_cents(w2.y, mu, sd);
+            }
+        }
+    }
+    st.total = MODE == 0 ? st.total : paid_cost;
+    return st;
+}
+
+struct RowsShared {
+    long long wave_part[kRowsBlock / kWave];
+    int wave_min[kRowsBlock / kWave];
+    long long remaining;
+    long long carry;
+    int cur;
+    int found;
+    int stopped;
+};
+
+// block-wide: smallest index in [lo, K) whose predicate holds, K if none.  pred is evaluated per lane.
+template <typename Pred>
+__device__ __forceinline__ int block_first(RowsShared &rs, int lo, int K, Pred pred)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int best = K;
+    for (int k = lo + tid; k < K; k += kRowsBlock)
+        if (pred(k)) { best = k; break; }        // a lane's indices ascend, the first hit is its smallest
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+    __syncthreads();
+    if (lane == 0) rs.wave_min[wv] = best;
+    __syncthreads();
+    int r = rs.wave_min[0];
+#pragma unroll
+    for (int i = 1; i < kRowsBlock / kWave; ++i) r = min(r, rs.wave_min[i]);
+    return r;
+}
+
+__global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const float *__restrict__ bids,
+                                                                const float *__restrict__ budget_in)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ RowsShared rs;
+    const int K = v.K;
+    // per keyword (persistent over the day)
+    unsigned long long *a_cost = reinterpret_cast<unsigned long long *>(lds_raw);        // [K]
+    unsigned long long *a_rev = a_cost + K;                                               // [K]
+    unsigned long long *c_total = a_rev + K;          // per cell of the current row: cost of clicked wins
+    unsigned long long *c_prefix = c_total + K;       // inclusive running total from `cur`
+    int *s_vol = reinterpret_cast<int *>(c_prefix + K);
+    unsigned int *a_imp = reinterpret_cast<unsigned int *>(s_vol + K);
+    unsigned int *a_clk = a_imp + K, *a_conv = a_clk + K;
+    unsigned int *c_wins = a_conv + K, *c_first = c_wins + K;
+    unsigned char *c_state = reinterpret_cast<unsigned char *>(c_first + K);   // 0 impressions only, 1 paid in full, 2 done, 3 not visited
+
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t key = v.key[env];
+    const uint32_t tick = v.tick[env];
+    const long long budget_c = adc::budget_to_cents(budget_in[env]);
+
+    if (v.env_cost[env] < budget_c) {            // the fast pass was exact for this env: only the tail remains
+        if (tid == 0) step_tail(v, env, tick, true, v.env_profit[env], 0.0);
+        return;
+    }
+
+    for (int k = tid; k < K; k += kRowsBlock) {
+        const adc::U4 w = adc::draw(key, 0u, adc::ST_VOL, (uint32_t)k, tick);
+        s_vol[k] = adc::volume_from_word(w.x, param_at(v, ADC_P_VOL_MEAN, env, k), param_at(v, ADC_P_VOL_STD, env, k));
+        a_imp[k] = a_clk[k] = a_conv[k] = 0u;
+        a_cost[k] = a_rev[k] = 0ull;
+    }
+    if (tid == 0) { rs.remaining = budget_c; rs.stopped = 0; }
+    __syncthreads();
+
+    for (int t = 0; t < adc::kTimesteps; ++t) {
+        // ---- pass A: statistics of every cell of the row
+        long long my_total = 0;
+        for (int k = tid; k < K; k += kRowsBlock) {
+            int32_t j0, n;
+            adc::cell_range(s_vol[k], t, j0, n);
+            unsigned int cv; unsigned long long rv, pc;
+            const CellStat st = walk_cell<0>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
+                                             param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
+                                             adc::bernoulli_threshold(param_at(v, ADC_P_BCTR, env, k)), 0ull, 0.f, 0.f, 0, cv, rv, pc);
+            c_wins[k] = st.wins;
+            c_first[k] = st.first;
+            c_total[k] = st.total;
+            c_state[k] = 1;
+            my_total += (long long)st.total;
+        }
+        my_total = wave_sum_i64(my_total);
+        if (lane == 0) rs.wave_part[wv] = my_total;
+        __syncthreads();
+        long long row_total = 0;
+#pragma unroll
+        for (int i = 0; i < kRowsBlock / kWave; ++i) row_total += rs.wave_part[i];
+        long long R = rs.remaining;
+        __syncthreads();
+
+        if (!(R - row_total > 0)) {
+            // ---- the row does not fit as a whole: resolve it in keyword order
+            int cur = 0;
+            bool stop = false;
+            while (cur < K && !stop) {
+                // (a) bulk: running total from `cur`; cells with prefix < R are paid in full
+                long long carry = 0;
+                int kfull = K;
+                for (int base = cur; base < K && kfull == K; base += kRowsBlock) {
+                    const int k = base + tid;
+                    const long long x = k < K ? (long long)c_total[k] : 0;
+                    long long incl = wave_scan_i64(x);
+                    if (lane == 63) rs.wave_part[wv] = incl;
+                    __syncthreads();
+                    long long wbase = carry;
+                    for (int i = 0; i < wv; ++i) wbase += rs.wave_part[i];
+                    long long tile_total = 0;
+                    for (int i = 0; i < kRowsBlock / kWave; ++i) tile_total += rs.wave_part[i];
+                    incl += wbase;
+                    if (k < K) c_prefix[k] = (unsigned long long)incl;
+                    __syncthreads();
+                    kfull = block_first(rs, base, min(K, base + kRowsBlock), [&](int kk) { return !((long long)c_prefix[kk] < R); });
+                    if (kfull >= min(K, base + kRowsBlock)) kfull = K;
+                    carry += tile_total;
+                }
+                // cells [cur, kfull) keep state 1 (paid in full)
+                if (kfull > cur) R -= (long long)c_prefix[kfull - 1];
+                __syncthreads();
+                cur = kfull;
+                if (cur >= K) break;
+                // (b) the cell that does not fit: its lane walks it click by click
+                if (tid == (cur % kRowsBlock)) {
+                    const int k = cur;
+                    int32_t j0, n;
+                    adc::cell_range(s_vol[k], t, j0, n);
+                    unsigned int cv; unsigned long long rv, pc;
+                    const CellStat st = walk_cell<2>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
+                                                     param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
+                                                     adc::bernoulli_threshold(param_at(v, ADC_P_BCTR, env, k)),
+                                                     adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, k)),
+                                                     param_at(v, ADC_P_REV_MEAN, env, k), param_at(v, ADC_P_REV_STD, env, k), R, cv, rv, pc);
+                    a_imp[k] += st.wins;
+                    a_clk[k] += st.clicks;
+                    a_cost[k] += pc;
+                    a_conv[k] += cv;
+                    a_rev[k] += rv;
+                    c_state[k] = 2;
+                    rs.carry = (long long)pc;
+                }
+                __syncthreads();
+                R -= rs.carry;
+                __syncthreads();
+                if (R <= 0) {                      // campaign stop (:230-233): later cells are never visited
+                    stop = true;
+                    for (int k = cur + 1 + tid; k < K; k += kRowsBlock) c_state[k] = 3;
+                    break;
+                }
+                cur += 1;
+                // (c) skip cells whose first click is unaffordable (they pay nothing, impressions still count)
+                const int knext = block_first(rs, cur, K, [&](int kk) { return (long long)c_first[kk] <= R; });
+                for (int k = cur + tid; k < knext; k += kRowsBlock) c_state[k] = 0;
+                __syncthreads();
+                cur = knext;
+            }
+            if (stop && tid == 0) rs.stopped = 1;
         } else {
-            reward = reward_d;
-            cum = v.cum[env] + reward;
-            v.cum[env] = cum;
+            R -= row_total;
         }
-        const bool truncated = cum < -v.loss_threshold;                 // :225
-        const int day = v.day[env] + 1;                                  // :227
-        const bool terminated = day >= v.max_days;                       // :228
-        v.reward[env] = reward;
-        v.cum_profit[env] = cum;
-        v.day_out[env] = day;
-        v.term[env] = terminated;
-        v.trunc[env] = truncated;
-        v.day[env] = day;
-        v.tick[env] = tick + 1u;
-        if (v.drift_on) v.drift_pending[env] = 1;                        // :246 update_keywords()
-        if (v.auto_reset && (terminated || truncated)) {
-            v.day[env] = 0; v.cum_cents[env] = 0; v.cum[env] = 0.0;      // :327-328
+        __syncthreads();
+        if (tid == 0) rs.remaining = R;
+        // ---- pass B: commit
+        for (int k = tid; k < K; k += kRowsBlock) {
+            const unsigned char stt = c_state[k];
+            if (stt == 0) a_imp[k] += c_wins[k];
+            else if (stt == 1) {
+                int32_t j0, n;
+                adc::cell_range(s_vol[k], t, j0, n);
+                unsigned int cv; unsigned long long rv, pc;
+                const CellStat st = walk_cell<1>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
+                                                 param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
+                                                 adc::bernoulli_threshold(param_at(v, ADC_P_BCTR, env, k)),
+                                                 adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, k)),
+                                                 param_at(v, ADC_P_REV_MEAN, env, k), param_at(v, ADC_P_REV_STD, env, k), 0, cv, rv, pc);
+                a_imp[k] += st.wins;
+                a_clk[k] += st.clicks;
+                a_cost[k] += pc;
+                a_conv[k] += cv;
+                a_rev[k] += rv;
+            }
         }
-        v.env_cost[env] = 0;
-        v.env_profit[env] = 0;
-        if (v.metrics_on) {
-            // per-env running sums (no same-address atomics: 4096 waves on one word serialise at ~12 ns each)
-            const long long pc = MODEL == ADC_MODEL_IMPLICIT ? profit_c : (long long)__double2ll_rn(reward * 100.0);
-            v.metric_env[env] += pc;
-            v.metric_env[(size_t)v.N + env] += 1;
-            if (terminated || truncated) v.metric_env[2 * (size_t)v.N + env] += 1;
-            if (truncated) v.metric_env[3 * (size_t)v.N + env] += 1;
-        }
+        __syncthreads();
+        if (rs.stopped) break;
+    }
+
+    // ---- observations and the step tail
+    long long pc = 0;
+    for (int k = tid; k < K; k += kRowsBlock) {
+        const size_t o = (size_t)env * K + k;
+        const long long c = (long long)a_cost[k], r = (long long)a_rev[k];
+        v.imp[o] = (int)a_imp[k];
+        v.clk[o] = (int)a_clk[k];
+        v.conv[o] = (int)a_conv[k];
+        v.cost[o] = (float)c / 100.0f;
+        v.rev[o] = (float)r / 100.0f;
+        pc += r - c;
+    }
+    pc = wave_sum_i64(pc);
+    __syncthreads();
+    if (lane == 0) rs.wave_part[wv] = pc;
+    __syncthreads();
+    if (tid == 0) {
+        long long profit_c = 0;
+        for (int i = 0; i < kRowsBlock / kWave; ++i) profit_c += rs.wave_part[i];
+        step_tail(v, env, tick, true, profit_c, 0.0);
     }
 }
 
@@ -1019,7 +1302,12 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
         hipLaunchKernelGGL(k_step_implicit_fast, dim3((unsigned)N * tiles), dim3(kFastBlock), 0, e->stream, v, d_bids);
         if (prof) { HIP_TRY(hipEventRecord(e->ev_b[e->ev_used], e->stream)); e->ev_used++; }
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((k_step_exact<ADC_MODEL_IMPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 1);
+        if (K <= kRowsMaxK) {
+            const size_t lds_rows = (size_t)K * (4 * 8 + 6 * 4 + 1) + 16;
+            hipLaunchKernelGGL(k_step_exact_rows, dim3(N), dim3(kRowsBlock), lds_rows, e->stream, v, d_bids, d_budget);
+        } else {
+            hipLaunchKernelGGL((k_step_exact<ADC_MODEL_IMPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 1);
+        }
     } else {
         hipLaunchKernelGGL((k_step_exact<ADC_MODEL_EXPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 0);
     }

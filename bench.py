@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", help="cfg2 (metric config), cfg3, cfg4, cfg5")
+    ap.add_argument("--budget", type=float, default=1.0e9, help="per-env daily budget in dollars (default: non-binding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -82,7 +83,7 @@ def main():
                      loss_threshold=1.0e12, drift_enabled=drift, auto_reset=True)
     eng.set_all_params(planes)
     eng.reset()
-    eng.sample_actions(0.30, 1.00, 1.0e9)        # actions resident in HBM before the timed region
+    eng.sample_actions(0.30, 1.00, args.budget)  # actions resident in HBM before the timed region
     eng.metrics_enable(True)
 
     from adcraft_amd import distributed as D, experiment_metrics as em
@@ -150,7 +151,7 @@ def main():
             "dtype": "i32 cents + f32 (Philox4x32-10 u32)", "data": "synthetic",
             "config": {"workload": f"{args.config}: {N} envs x {K} keywords per GPU, IMPLICIT keywords, "
                                    f"mean_volume {mean_volume}, cvr {cvr}, no_vol_prob {no_vol_prob}, drift {drift}, "
-                                   f"budget non-binding, {max_days}-step episodes with auto-reset",
+                                   f"budget {'non-binding' if args.budget >= 1e8 else args.budget}, {max_days}-step episodes with auto-reset",
                        "envs_per_gpu": N, "keywords": K, "parallelism": f"env-sharded x{world}"},
             "env_steps_per_s": float(world) * N * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

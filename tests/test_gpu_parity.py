@@ -360,3 +360,18 @@ def test_metric_accumulators(amd):
     kp, sc = e.metrics_read()
     assert np.array_equal(kp, prof) and sc[0] == tot and sc[1] == 4 * N and sc[2] == N and sc[3] == 0
     e.close()
+
+
+# ------------------------------------------------------------------ row-parallel exact pass: more shapes / edge budgets
+@pytest.mark.parametrize("N,K,budget", [(3, 300, 120.0), (2, 1024, 400.0), (4, 257, 3.0), (3, 64, 0.0), (2, 64, -5.0),
+                                        (2, 1500, 500.0)])
+def test_exact_rows_shapes_and_edge_budgets(amd, N, K, budget):
+    planes = H.implicit_params(N, K, seed=41 + K)
+    _run_vs_oracle(amd, N, K, planes, steps=2, budget=budget, bid_lo=0.4, bid_hi=1.1)
+
+
+def test_exact_pass_sparse_and_large_cells(amd):
+    planes = H.implicit_params(3, 200, seed=43, mean_volume=16, cvr=0.5, no_vol_prob=0.5)
+    _run_vs_oracle(amd, 3, 200, planes, steps=3, budget=2.0)
+    planes = H.implicit_params(2, 24, seed=44, mean_volume=2500)        # cells of ~100 auctions
+    _run_vs_oracle(amd, 2, 24, planes, steps=2, budget=700.0)
