@@ -66,7 +66,8 @@ int fail(int code, const std::string &msg)
 constexpr int kFastBlock = 256;   // lanes per workgroup = keywords per tile
 constexpr int kChunk = 16;        // auctions per work item
 constexpr int kWave = 64;
-constexpr int kProfileRing = 8192;
+constexpr int kProfileRing = 2048;   // steps in flight between profile flushes
+constexpr int kProfileMarks = 4;     // events per step: before fast | after fast | after exact/tail | after metric
 
 // -------------------------------------------------------------------------------------------------
 // device view of the engine (passed by value to kernels)
@@ -86,6 +87,7 @@ struct View {
     int64_t *cum_cents;       // [N] IMPLICIT
     double *cum;              // [N] EXPLICIT
     uint8_t *drift_pending;   // [N]
+    uint8_t *exact_hint;      // [N] budget bound on the previous step: skip the fast pass, go straight to the exact one
     // per-step scratch
     int64_t *env_cost;        // [N] cents spent by the fast pass
     int64_t *env_profit;      // [N]
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
     const uint64_t key = v.key[env];
     const uint32_t tick = v.tick[env];
     const bool drift = v.drift_on && v.drift_pending[env];
+    if (v.exact_hint[env]) return;      // scheduling hint only: k_step_exact_rows computes this env (same results)
 
     // ---- phase 1: one lane per keyword ---------------------------------------------------------
     int V = 0;
@@ -792,12 +795,22 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
     const uint32_t tick = v.tick[env];
     const long long budget_c = adc::budget_to_cents(budget_in[env]);
 
-    if (v.env_cost[env] < budget_c) {            // the fast pass was exact for this env: only the tail remains
+    const bool hinted = v.exact_hint[env] != 0;
+    if (!hinted && v.env_cost[env] < budget_c) {      // the fast pass was exact for this env: only the tail remains
         if (tid == 0) step_tail(v, env, tick, true, v.env_profit[env], 0.0);
         return;
     }
+    const bool drift = hinted && v.drift_on && v.drift_pending[env];    // the skipped fast pass would have applied it
+    bool was_binding = false;
 
     for (int k = tid; k < K; k += kRowsBlock) {
+        if (drift) {
+            float vm = param_at(v, ADC_P_VOL_MEAN, env, k), bc = param_at(v, ADC_P_BCTR, env, k), sc = param_at(v, ADC_P_SCTR, env, k);
+            drift_keyword(v, key, tick - 1u, k, vm, param_at(v, ADC_P_VOL_STD, env, k), bc, sc);
+            param_at(v, ADC_P_VOL_MEAN, env, k) = vm;
+            param_at(v, ADC_P_BCTR, env, k) = bc;
+            param_at(v, ADC_P_SCTR, env, k) = sc;
+        }
         const adc::U4 w = adc::draw(key, 0u, adc::ST_VOL, (uint32_t)k, tick);
         s_vol[k] = adc::volume_from_word(w.x, param_at(v, ADC_P_VOL_MEAN, env, k), param_at(v, ADC_P_VOL_STD, env, k));
         a_imp[k] = a_clk[k] = a_conv[k] = 0u;
@@ -833,6 +846,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
 
         if (!(R - row_total > 0)) {
             // ---- the row does not fit as a whole: resolve it in keyword order
+            was_binding = true;
             int cur = 0;
             bool stop = false;
             while (cur < K && !stop) {
@@ -944,6 +958,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
     if (tid == 0) {
         long long profit_c = 0;
         for (int i = 0; i < kRowsBlock / kWave; ++i) profit_c += rs.wave_part[i];
+        v.exact_hint[env] = was_binding ? 1 : 0;
         step_tail(v, env, tick, true, profit_c, 0.0);
     }
 }
@@ -1244,9 +1259,9 @@ struct adc_engine {
     std::vector<void *> allocs;
     bool have_reset = false;
     bool profiling = false;
-    std::vector<hipEvent_t> ev_a, ev_b;
+    std::vector<hipEvent_t> ev;          // [kProfileRing][kProfileMarks]
     int ev_used = 0;
-    double prof_ms = 0.0;
+    double prof_ms[3] = {0.0, 0.0, 0.0};   // fast pass | exact pass + tail | metric accumulate
     int64_t prof_launches = 0;
     size_t flat_obs_bytes = 0;
     float *d_flat_obs = nullptr;
@@ -1270,10 +1285,13 @@ int dev_alloc(adc_engine *e, T **p, size_t count)
 int flush_profile(adc_engine *e)
 {
     for (int i = 0; i < e->ev_used; ++i) {
-        float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(e->ev_b[i]));
-        HIP_TRY(hipEventElapsedTime(&ms, e->ev_a[i], e->ev_b[i]));
-        e->prof_ms += ms;
+        hipEvent_t *m = &e->ev[(size_t)i * kProfileMarks];
+        HIP_TRY(hipEventSynchronize(m[kProfileMarks - 1]));
+        for (int j = 0; j < 3; ++j) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, m[j], m[j + 1]));
+            e->prof_ms[j] += ms;
+        }
         e->prof_launches += 1;
     }
     e->ev_used = 0;
@@ -1294,14 +1312,15 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
         HIP_TRY(hipGetLastError());
         return ADC_OK;
     }
+    const bool prof = e->profiling;
+    if (prof && e->ev_used == kProfileRing) { int rc = flush_profile(e); if (rc) return rc; }
+    hipEvent_t *mark = prof ? &e->ev[(size_t)e->ev_used * kProfileMarks] : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(mark[0], e->stream));
     if (implicit) {
         const int tiles = (K + kFastBlock - 1) / kFastBlock;
-        const bool prof = e->profiling;
-        if (prof && e->ev_used == kProfileRing) { int rc = flush_profile(e); if (rc) return rc; }
-        if (prof) HIP_TRY(hipEventRecord(e->ev_a[e->ev_used], e->stream));
         hipLaunchKernelGGL(k_step_implicit_fast, dim3((unsigned)N * tiles), dim3(kFastBlock), 0, e->stream, v, d_bids);
-        if (prof) { HIP_TRY(hipEventRecord(e->ev_b[e->ev_used], e->stream)); e->ev_used++; }
         HIP_TRY(hipGetLastError());
+        if (prof) HIP_TRY(hipEventRecord(mark[1], e->stream));
         if (K <= kRowsMaxK) {
             const size_t lds_rows = (size_t)K * (4 * 8 + 6 * 4 + 1) + 16;
             hipLaunchKernelGGL(k_step_exact_rows, dim3(N), dim3(kRowsBlock), lds_rows, e->stream, v, d_bids, d_budget);
@@ -1309,14 +1328,17 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
             hipLaunchKernelGGL((k_step_exact<ADC_MODEL_IMPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 1);
         }
     } else {
+        if (prof) HIP_TRY(hipEventRecord(mark[1], e->stream));
         hipLaunchKernelGGL((k_step_exact<ADC_MODEL_EXPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 0);
     }
     HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(mark[2], e->stream));
     if (v.metrics_on) {
         const size_t nk = (size_t)N * K;
         hipLaunchKernelGGL(k_metric_accumulate, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, e->stream, v);
         HIP_TRY(hipGetLastError());
     }
+    if (prof) { HIP_TRY(hipEventRecord(mark[3], e->stream)); e->ev_used++; }
     return ADC_OK;
 }
 
@@ -1360,8 +1382,7 @@ ADC_EXPORT void adc_engine_destroy(adc_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_id);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (auto ev : e->ev_a) (void)hipEventDestroy(ev);
-    for (auto ev : e->ev_b) (void)hipEventDestroy(ev);
+    for (auto ev : e->ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1400,7 +1421,7 @@ ADC_EXPORT int adc_engine_create(const adc_config *cfg, adc_engine **out)
     const size_t N = v.N, K = v.K, NK = N * K;
 #define A(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count))) != ADC_OK) return bail(rc)
     A(v.params, ADC_P_COUNT * NK);
-    A(v.key, N); A(v.tick, N); A(v.day, N); A(v.cum_cents, N); A(v.cum, N); A(v.drift_pending, N);
+    A(v.key, N); A(v.tick, N); A(v.day, N); A(v.cum_cents, N); A(v.cum, N); A(v.drift_pending, N); A(v.exact_hint, N);
     A(v.env_cost, N); A(v.env_profit, N);
     A(v.imp, NK); A(v.clk, NK); A(v.conv, NK); A(v.cost, NK); A(v.rev, NK);
     A(v.reward, N); A(v.cum_profit, N); A(v.day_out, N); A(v.term, N); A(v.trunc, N);
@@ -1712,13 +1733,9 @@ ADC_EXPORT int adc_engine_set_flat_actions_device(adc_engine *e, const float *d_
 ADC_EXPORT int adc_engine_profile_enable(adc_engine *e, int enabled)
 {
     ENGINE_GUARD(e);
-    if (enabled && e->ev_a.empty()) {
-        e->ev_a.resize(kProfileRing);
-        e->ev_b.resize(kProfileRing);
-        for (int i = 0; i < kProfileRing; ++i) {
-            HIP_TRY(hipEventCreate(&e->ev_a[i]));
-            HIP_TRY(hipEventCreate(&e->ev_b[i]));
-        }
+    if (enabled && e->ev.empty()) {
+        e->ev.resize((size_t)kProfileRing * kProfileMarks);
+        for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     }
     e->profiling = enabled != 0;
     return ADC_OK;
@@ -1729,9 +1746,9 @@ ADC_EXPORT int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, i
     ENGINE_GUARD(e);
     int rc = flush_profile(e);
     if (rc) return rc;
-    if (kernel_ms_total) *kernel_ms_total = e->prof_ms;
+    if (kernel_ms_total) for (int j = 0; j < 3; ++j) kernel_ms_total[j] = e->prof_ms[j];
     if (launches) *launches = e->prof_launches;
-    e->prof_ms = 0.0;
+    e->prof_ms[0] = e->prof_ms[1] = e->prof_ms[2] = 0.0;
     e->prof_launches = 0;
     return ADC_OK;
 }

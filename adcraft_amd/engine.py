@@ -160,10 +160,11 @@ class StepEngine:
         check(self._lib.adc_engine_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self):
-        ms = C.c_double()
+        """(ms_fast_pass, ms_exact_pass_and_tail, ms_metric_accumulate), steps - summed over the steps since the last read"""
+        ms = (C.c_double * 3)()
         n = C.c_int64()
-        check(self._lib.adc_engine_profile_read(self._h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        check(self._lib.adc_engine_profile_read(self._h, ms, C.byref(n)))
+        return tuple(ms), n.value
 
     def metrics_enable(self, on=True):
         check(self._lib.adc_engine_metrics_enable(self._h, 1 if on else 0))

@@ -132,13 +132,15 @@ def main():
         units = float(world) * N * K * args.steps
         auctions = None
         b_alg = BYTES_PER_U[drift] * N * K + BYTES_PER_ENV * N            # algorithmic bytes per launch (one GPU)
-        k_ms = kernel_ms / max(launches, 1)
+        k_ms = kernel_ms[dom] / max(launches, 1)
         achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
+        names = ("k_step_implicit_fast", "k_step_exact_rows (+ step tail)", "k_metric_accumulate")
+        dom = int(np.argmax(kernel_ms))              # the dominant kernel of the step
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch") if dom == 0 else None
             except Exception:
                 traffic = None
         line = {
@@ -156,7 +158,8 @@ def main():
             "env_steps_per_s": float(world) * N * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_step_implicit_fast", "kernel_ms": k_ms, "launches": int(launches),
+                         "kernel": names[dom], "kernel_ms": k_ms, "launches": int(launches),
+                         "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(names, kernel_ms)},
                          "algorithmic_bytes_per_launch": b_alg},
         }
         profit_c, ideal, sc = D.unpack_metric_vector(totals, K)

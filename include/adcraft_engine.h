@@ -189,9 +189,10 @@ int adc_engine_sample_actions(adc_engine *e, float bid_lo, float bid_hi, float b
 int adc_engine_set_flat_actions_device(adc_engine *e, const float *d_flat_n_k1);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
-/* when enabled, every launch of the dominant step kernel is bracketed by HIP events on the engine stream */
+/* when enabled, the kernels of every step are bracketed by HIP events on the engine stream */
 int adc_engine_profile_enable(adc_engine *e, int enabled);
-/* sum of kernel durations and number of launches since enable/last read; resets the counters */
+/* kernel_ms_total[3] = summed durations of {fast pass, exact pass + step tail, metric accumulate} over `launches`
+ * steps since enable / the last read; resets the counters */
 int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, int64_t *launches);
 
 /* ---- episode metrics (adcraft/experiment_utils/experiment_metrics.py:64-83) ----------------------- */
