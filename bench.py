@@ -66,11 +66,16 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    backend = os.environ.get("ADCRAFT_DIST_BACKEND", "nccl")     # "gloo" lets the N>1 path be rehearsed on one GPU
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_device = "cuda" if backend == "nccl" else None
 
     from adcraft_amd import _ffi, synthetic
     from adcraft_amd.engine import StepEngine
@@ -79,7 +84,8 @@ def main():
     max_days = 60
     planes = synthetic.implicit_keyword_planes(N, K, seed=1729 + rank, mean_volume=mean_volume, cvr=cvr,
                                                no_vol_prob=no_vol_prob)
-    eng = StepEngine(N, K, device_id=local_rank, seed=1729, env_id_base=rank * N, max_days=max_days,
+    n_dev = max(_ffi.device_count(), 1)
+    eng = StepEngine(N, K, device_id=local_rank % n_dev, seed=1729, env_id_base=rank * N, max_days=max_days,
                      loss_threshold=1.0e12, drift_enabled=drift, auto_reset=True)
     eng.set_all_params(planes)
     eng.reset()
@@ -95,7 +101,7 @@ def main():
         kp, sc = eng.metrics_read()
         vec = D.pack_metric_vector(kp, ideal_k * steps_done, sc)
         if dist is not None:
-            vec = D.all_reduce_sum(vec, device="cuda")
+            vec = D.all_reduce_sum(vec, device=red_device)
         return vec
 
     def barrier():
@@ -103,7 +109,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         eng.step_device()
@@ -124,18 +131,17 @@ def main():
     totals = metric_allreduce(args.steps)
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         units = float(world) * N * K * args.steps
-        auctions = None
         b_alg = BYTES_PER_U[drift] * N * K + BYTES_PER_ENV * N            # algorithmic bytes per launch (one GPU)
-        k_ms = kernel_ms[dom] / max(launches, 1)
-        achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
         names = ("k_step_implicit_fast", "k_step_exact_rows (+ step tail)", "k_metric_accumulate")
         dom = int(np.argmax(kernel_ms))              # the dominant kernel of the step
+        k_ms = kernel_ms[dom] / max(launches, 1)
+        achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
