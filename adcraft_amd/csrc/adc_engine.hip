@@ -102,6 +102,7 @@ struct View {
     int64_t *metric_scalars;     // [8] (filled on read)
     int64_t *metric_env;         // [4][N] per-env running sums: profit cents, env steps, episodes, truncations
     int64_t *metric_kw;          // [N][K] running sum of keyword profit, cents (metric mode)
+    float *flat_obs;             // [N][5K+2] FlatArrayWrapper layout, written after every step when enabled
 };
 
 __device__ __forceinline__ float &param_at(const View &v, int p, int env, int k)
@@ -390,8 +391,7 @@ struct TapeView {
     int64_t len_bid, len_ximp, len_xcost, len_click, len_conv, len_rev;
 };
 
-// dynamic LDS layout (K entries each): vol i32, imp i32, clk i32, conv i32, cost i64|f64, rev i64, profit f64
-__device__ __forceinline__ size_t exact_lds_bytes(int K) { return (size_t)K * (4 * 4 + 3 * 8); }
+// dynamic LDS layout (K entries each): cost i64|f64, rev i64, profit f64, vol i32, imp i32, clk i32, conv i32
 
 template <int MODEL, bool TAPE>
 __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__restrict__ bids,
@@ -1198,6 +1198,29 @@ __global__ void k_sample_actions(View v, float lo, float hi, float budget, float
     if (k == 0) budgets[env] = budget;
 }
 
+// flat observation row = sorted-key concatenation of the obs dict (adcraft/gymnasium_kw_utils.py:383-390,
+// adcraft/wrappers/flat_array.py:74-80): buyside_clicks[K] | cost[K] | cumulative_profit | days_passed |
+// impressions[K] | revenue[K] | sellside_conversions[K], all float32
+__global__ void k_flatten_obs(View v)
+{
+    const int env = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = v.K;
+    float *row = v.flat_obs + (size_t)env * (5 * K + 2);
+    if (k < K) {
+        const size_t o = (size_t)env * K + k;
+        row[k] = (float)v.clk[o];
+        row[K + k] = v.cost[o];
+        row[2 * K + 2 + k] = (float)v.imp[o];
+        row[3 * K + 2 + k] = v.rev[o];
+        row[4 * K + 2 + k] = (float)v.conv[o];
+    }
+    if (k == 0) {
+        row[2 * K] = (float)v.cum_profit[env];
+        row[2 * K + 1] = (float)v.day_out[env];
+    }
+}
+
 __global__ void k_unflatten_actions(View v, const float *flat, float *bids, float *budgets)
 {
     // FlatArrayWrapper action = [budget, keyword_bids...] (sorted keys, adcraft/wrappers/flat_array.py:52,76)
@@ -1310,6 +1333,10 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
         if (implicit) hipLaunchKernelGGL((k_step_exact<ADC_MODEL_IMPLICIT, true>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, *tape, 0);
         else hipLaunchKernelGGL((k_step_exact<ADC_MODEL_EXPLICIT, true>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, *tape, 0);
         HIP_TRY(hipGetLastError());
+        if (v.flat_obs) {
+            hipLaunchKernelGGL(k_flatten_obs, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), 0, e->stream, v);
+            HIP_TRY(hipGetLastError());
+        }
         return ADC_OK;
     }
     const bool prof = e->profiling;
@@ -1336,6 +1363,10 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
     if (v.metrics_on) {
         const size_t nk = (size_t)N * K;
         hipLaunchKernelGGL(k_metric_accumulate, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, e->stream, v);
+        HIP_TRY(hipGetLastError());
+    }
+    if (v.flat_obs) {
+        hipLaunchKernelGGL(k_flatten_obs, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), 0, e->stream, v);
         HIP_TRY(hipGetLastError());
     }
     if (prof) { HIP_TRY(hipEventRecord(mark[3], e->stream)); e->ev_used++; }
@@ -1696,6 +1727,9 @@ ADC_EXPORT int adc_engine_device_buffer(adc_engine *e, int buffer_id, void **dpt
     case ADC_BUF_TRUNCATED: p = v.trunc; b = N; break;
     case ADC_BUF_METRIC_PROFIT: p = v.metric_profit; b = K * 8; break;
     case ADC_BUF_METRIC_SCALARS: p = v.metric_scalars; b = 8 * 8; break;
+    case ADC_BUF_FLAT_OBS:
+        if (!v.flat_obs) return fail(ADC_ESTATE, "flat observations are not enabled (adc_engine_flat_obs_enable)");
+        p = v.flat_obs; b = N * (5 * K + 2) * 4; break;
     default: return fail(ADC_EINVAL, "unknown buffer id");
     }
     *dptr = p;
@@ -1727,6 +1761,18 @@ ADC_EXPORT int adc_engine_set_flat_actions_device(adc_engine *e, const float *d_
     hipLaunchKernelGGL(k_unflatten_actions, dim3((unsigned)((e->v.K + 255) / 256), (unsigned)e->v.N), dim3(256), 0, e->stream, e->v,
                        d_flat, e->d_bids, e->d_budget);
     HIP_TRY(hipGetLastError());
+    return ADC_OK;
+}
+
+ADC_EXPORT int adc_engine_flat_obs_enable(adc_engine *e, int enabled)
+{
+    ENGINE_GUARD(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (enabled && !e->d_flat_obs) {
+        int rc = dev_alloc(e, &e->d_flat_obs, (size_t)e->v.N * (5 * (size_t)e->v.K + 2));
+        if (rc) return rc;
+    }
+    e->v.flat_obs = enabled ? e->d_flat_obs : nullptr;
     return ADC_OK;
 }
 

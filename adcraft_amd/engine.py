@@ -144,6 +144,13 @@ class StepEngine:
     def sample_actions(self, bid_lo=0.30, bid_hi=1.00, budget=1.0e9):
         check(self._lib.adc_engine_sample_actions(self._h, bid_lo, bid_hi, budget))
 
+    def flat_obs_enable(self, on=True):
+        check(self._lib.adc_engine_flat_obs_enable(self._h, 1 if on else 0))
+
+    def set_flat_actions_device(self, d_flat_ptr):
+        """device pointer to float32 [N][K+1] = [budget, bids...] -> the engine's staging buffers (async)"""
+        check(self._lib.adc_engine_set_flat_actions_device(self._h, d_flat_ptr))
+
     def device_buffer(self, buffer_id):
         p = C.c_void_p()
         n = C.c_size_t()

@@ -185,6 +185,10 @@ int adc_engine_stream(adc_engine *e, void **hip_stream);
 /* fill the engine's action staging buffers with synthetic actions: bid = round2(U(lo,hi)) from the
  * engine's ACTION stream at the current tick, budget = `budget` for every env */
 int adc_engine_sample_actions(adc_engine *e, float bid_lo, float bid_hi, float budget);
+/* emit FlatArrayWrapper-compatible observations [N][5K+2] float32 on the device after every step
+ * (sorted-key order: buyside_clicks, cost, cumulative_profit, days_passed, impressions, revenue,
+ * sellside_conversions; adcraft/wrappers/flat_array.py:74-80).  Read it through ADC_BUF_FLAT_OBS. */
+int adc_engine_flat_obs_enable(adc_engine *e, int enabled);
 /* FlatArrayWrapper-compatible action [N][K+1] = [budget, bids...] (device pointer) -> staging buffers */
 int adc_engine_set_flat_actions_device(adc_engine *e, const float *d_flat_n_k1);
 

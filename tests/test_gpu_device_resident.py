@@ -1,0 +1,128 @@
+"""-m gpu: the device-resident side of the ABI - external device pointers for actions (torch tensors, used
+here only as a device allocator), flat actions / flat observations emitted on the device, zero-copy reads."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    return torch
+
+
+def _view(torch, ptr, nbytes, dtype, shape):
+    """zero-copy torch view of an engine buffer via __cuda_array_interface__"""
+    class _Buf:
+        pass
+    b = _Buf()
+    np_dt = np.dtype(dtype)
+    b.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": np_dt.str, "data": (ptr, False), "version": 2}
+    assert int(np.prod(shape)) * np_dt.itemsize == nbytes
+    return torch.as_tensor(b, device="cuda")
+
+
+def test_step_with_external_device_actions_and_flat_io(torch_cuda):
+    torch = torch_cuda
+    from adcraft_amd import _ffi, gymnasium_kw_utils as utils
+    from adcraft_amd.engine import StepEngine
+    N, K = 64, 96
+    planes = H.implicit_params(N, K, seed=51)
+    bids = np.random.default_rng(2).uniform(0.3, 1.0, (N, K)).astype(np.float32)
+    budget = np.full(N, 500.0, np.float32)
+
+    ref = StepEngine(N, K, seed=11)
+    ref.set_all_params(planes)
+    ref.reset()
+    want = ref.step(bids, budget)
+    ref.close()
+
+    # (1) caller-owned device buffers
+    e = StepEngine(N, K, seed=11)
+    e.set_all_params(planes)
+    e.reset()
+    e.flat_obs_enable(True)
+    d_bids, d_budget = torch.from_numpy(bids).cuda(), torch.from_numpy(budget).cuda()
+    torch.cuda.synchronize()
+    e.step_device(d_bids.data_ptr(), d_budget.data_ptr())
+    got = e.fetch()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    # flat observations written on the device == FlatArrayWrapper order of the dict observation
+    p, nbytes = e.device_buffer(_ffi.BUF_FLAT_OBS)
+    flat = _view(torch, p, nbytes, np.float32, (N, 5 * K + 2)).cpu().numpy()
+    for i in (0, N - 1):
+        obs = dict(impressions=got["impressions"][i], buyside_clicks=got["buyside_clicks"][i], cost=got["cost"][i],
+                   sellside_conversions=got["sellside_conversions"][i], revenue=got["revenue"][i],
+                   cumulative_profit=np.array([got["cumulative_profit"][i]]), days_passed=np.array([got["days_passed"][i]]))
+        assert np.array_equal(flat[i], utils.flatten_dict_array(obs).astype(np.float32))
+    # zero-copy read of an output buffer
+    p, nbytes = e.device_buffer(_ffi.BUF_IMPRESSIONS)
+    assert np.array_equal(_view(torch, p, nbytes, np.int32, (N, K)).cpu().numpy(), got["impressions"])
+    e.close()
+
+    # (2) flat device actions [budget, bids...] -> same step
+    e = StepEngine(N, K, seed=11)
+    e.set_all_params(planes)
+    e.reset()
+    flat_act = torch.from_numpy(np.concatenate([budget[:, None], bids], axis=1)).cuda()
+    torch.cuda.synchronize()
+    e.set_flat_actions_device(flat_act.data_ptr())
+    e.step_device()
+    got2 = e.fetch()
+    for k in want:
+        assert np.array_equal(got2[k], want[k]), k
+    with pytest.raises(AssertionError):
+        e.device_buffer(_ffi.BUF_FLAT_OBS)          # not enabled on this engine
+    e.close()
+
+
+def test_bad_arguments_raise():
+    from adcraft_amd import _ffi
+    from adcraft_amd.engine import StepEngine
+    with pytest.raises(ValueError):
+        StepEngine(0, 4)
+    with pytest.raises(ValueError):
+        StepEngine(1, 5000)              # K > 4096
+    with pytest.raises(ValueError):
+        StepEngine(1, 4, device_id=99)
+    e = StepEngine(2, 4)
+    with pytest.raises(ValueError):
+        e.reset(env_mask=np.ones(3, np.uint8))
+    with pytest.raises(ValueError):
+        e.device_buffer(77)
+    with pytest.raises(ValueError):
+        e.set_params(9, np.zeros((2, 4)))
+    e.reset(env_mask=np.array([1, 0], np.uint8))
+    e.close()
+    e.close()                            # idempotent
+    assert _ffi.lib().adc_last_error() is not None
+
+
+def test_engine_checkpoint_resume(torch_cuda):
+    """state = params + rng state + episode state: a restored engine continues bit-identically"""
+    from adcraft_amd.engine import StepEngine
+    N, K = 8, 40
+    planes = H.implicit_params(N, K, seed=52)
+    bids = np.random.default_rng(3).uniform(0.3, 1.0, (N, K)).astype(np.float32)
+    a = StepEngine(N, K, seed=4, drift_enabled=True)
+    a.set_all_params(planes)
+    a.reset()
+    for _ in range(3):
+        a.step(bids, 1e9)
+    params, (keys, ticks), (day, cum) = a.get_all_params(), a.get_rng_state(), a.get_episode_state()
+    b = StepEngine(N, K, seed=999, drift_enabled=True)
+    b.set_all_params(params)
+    b.set_rng_state(keys, ticks)
+    b.set_episode_state(day, cum)
+    for _ in range(2):
+        x, y = a.step(bids, 1e9), b.step(bids, 1e9)
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    a.close()
+    b.close()
