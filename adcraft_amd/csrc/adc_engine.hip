@@ -170,6 +170,7 @@ struct FastShared {
     int bid_c[kFastBlock];
     float loc[kFastBlock], scale[kFastBlock], mu[kFastBlock], sd[kFastBlock];
     unsigned long long t_click[kFastBlock], t_conv[kFastBlock];       // Bernoulli thresholds
+    unsigned int m_click[kFastBlock], m_noclick[kFastBlock];           // AuctionLaw rescale multipliers
     unsigned int a_imp[kFastBlock], a_clk[kFastBlock], a_conv[kFastBlock];
     unsigned long long a_cost[kFastBlock], a_rev[kFastBlock];
     unsigned int queue[kFastBlock / kWave][kQueueCap];
@@ -209,7 +210,10 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         sh.scale[tid] = param_at(v, ADC_P_B, env, k);
         sh.mu[tid] = param_at(v, ADC_P_REV_MEAN, env, k);
         sh.sd[tid] = param_at(v, ADC_P_REV_STD, env, k);
-        sh.t_click[tid] = adc::bernoulli_threshold(bctr);
+        const adc::AuctionLaw law = adc::make_auction_law(bctr);
+        sh.t_click[tid] = law.t_click;
+        sh.m_click[tid] = law.m_click;
+        sh.m_noclick[tid] = law.m_noclick;
         sh.t_conv[tid] = adc::bernoulli_threshold(sctr);
         sh.bid_c[tid] = (int)adc::bid_to_cents(bids[(size_t)env * v.K + k]);
         const adc::U4 w = adc::draw(key, 0u, adc::ST_VOL, (uint32_t)k, tick);
@@ -268,35 +272,41 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         }
         const int bid_c = sh.bid_c[u];
         const float loc = sh.loc[u], scale = sh.scale[u];
-        const unsigned long long t_click = sh.t_click[u];
+        const adc::AuctionLaw law{sh.t_click[u], sh.m_click[u], sh.m_noclick[u]};
         const uint32_t kw = kw_base + (uint32_t)u;
         const unsigned int tag = (unsigned int)u << 24;
         unsigned int imp = 0, clk = 0;
         unsigned long long cost = 0;
-        for (int i = 0; i < kChunk; i += 2) {
-            const bool a0 = i < n, a1 = i + 1 < n;
-            if (!__any(a0)) break;
-            const adc::U4 w = adc::draw(key, (uint32_t)(j0 + i) >> 1, adc::ST_AUCTION, kw, tick);
-            const int comp0 = adc::laplace_cents(w.x, loc, scale);
-            const int comp1 = adc::laplace_cents(w.z, loc, scale);
-            const bool win0 = a0 && bid_c > comp0;                          // tie loses (helpers.py:167-170)
-            const bool win1 = a1 && bid_c > comp1;
-            const bool click0 = win0 && adc::bernoulli(w.y, t_click);
-            const bool click1 = win1 && adc::bernoulli(w.w, t_click);
-            imp += (unsigned int)win0 + (unsigned int)win1;
-            clk += (unsigned int)click0 + (unsigned int)click1;
-            cost += (click0 ? (unsigned long long)comp0 : 0ull) + (click1 ? (unsigned long long)comp1 : 0ull);  // 2nd price
-            const unsigned long long m0 = __ballot(click0), m1 = __ballot(click1);
-            if (click0) ring[(qtail + __popcll(m0 & lt)) & (kQueueCap - 1)] = tag | (unsigned int)(j0 + i);
-            qtail += __popcll(m0);
-            if (click1) ring[(qtail + __popcll(m1 & lt)) & (kQueueCap - 1)] = tag | (unsigned int)(j0 + i + 1);
-            qtail += __popcll(m1);
+        // one auction: 2nd-price clearing against the sampled competitor bid, click, deferred conversion
+        auto auction = [&](uint32_t word, int j, bool active) {
+            bool click_bit;
+            const int comp = adc::auction_outcome(word, law, loc, scale, click_bit);
+            const bool win = active && bid_c > comp;                       // tie loses (helpers.py:167-170)
+            const bool click = win && click_bit;
+            imp += (unsigned int)win;
+            clk += (unsigned int)click;
+            cost += click ? (unsigned long long)comp : 0ull;               // 2nd price = the competitor's bid
+            const unsigned long long m = __ballot(click);
+            if (click) ring[(qtail + __popcll(m & lt)) & (kQueueCap - 1)] = tag | (unsigned int)j;
+            qtail += __popcll(m);
+        };
+        auto drain = [&]() {
             while (qtail - qhead >= (unsigned int)kWave) {      // <= 63 + 128 entries can be waiting (ring holds 256)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 resolve_click(qhead + lane);
                 qhead += kWave;
             }
+        };
+        for (int i = 0; i < kChunk; i += 4) {
+            if (!__any(i < n)) break;
+            const adc::U4 w = adc::draw(key, (uint32_t)(j0 + i) >> 2, adc::ST_AUCTION, kw, tick);
+            auction(w.x, j0 + i, i < n);
+            auction(w.y, j0 + i + 1, i + 1 < n);
+            drain();
+            auction(w.z, j0 + i + 2, i + 2 < n);
+            auction(w.w, j0 + i + 3, i + 3 < n);
+            drain();
         }
         if (imp) atomicAdd(&sh.a_imp[u], imp);
         if (clk) {
@@ -470,20 +480,21 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
 
                 if (MODEL == ADC_MODEL_IMPLICIT) {
                     const float loc = param_at(v, ADC_P_A, env, k), scale = param_at(v, ADC_P_B, env, k);
+                    const adc::AuctionLaw law = adc::make_auction_law(param_at(v, ADC_P_BCTR, env, k));
                     int wins = 0, paid = 0, convs = 0;
                     long long clicked_sum = 0, cell_cost = 0, cell_rev = 0;
                     for (int base = 0; base < n; base += kWave) {
                         const int i = base + lane;
                         const bool act = i < n;
-                        uint32_t wclick = 0;
+                        bool click_bit = false;
                         long long comp = 0;
                         const uint32_t j = (uint32_t)(j0 + i);
                         if (act) {
                             if (TAPE) comp = tp.bid_cents[cur_bid + i];
                             else {
-                                const adc::U4 w = adc::draw(key, j >> 1, adc::ST_AUCTION, (uint32_t)k, tick);
-                                comp = adc::laplace_cents((j & 1u) ? w.z : w.x, loc, scale);
-                                wclick = (j & 1u) ? w.w : w.y;
+                                const adc::U4 w = adc::draw(key, j >> 2, adc::ST_AUCTION, (uint32_t)k, tick);
+                                const uint32_t word = (j & 3u) == 0 ? w.x : (j & 3u) == 1 ? w.y : (j & 3u) == 2 ? w.z : w.w;
+                                comp = adc::auction_outcome(word, law, loc, scale, click_bit);
                             }
                         }
                         const bool win = act && bid_c > comp;
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
                         bool clicked = false;
                         if (win) {
                             if (TAPE) clicked = tp.click[cur_click + wins + __popcll(win_mask & lt)] != 0;
-                            else clicked = adc::bernoulli(wclick, t_click);
+                            else clicked = click_bit;
                         }
                         // budget walk (bidding_simulation.py:97-104): click i is paid iff the running
                         // sum of clicked costs up to and including it fits the cell's opening budget
@@ -700,7 +711,7 @@ struct CellStat {
 // running cost fits `budget` (the reference's in-cell loop); `paid_cost` returns what was spent.
 template <int MODE>
 __device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint32_t kw, int j0, int n, int bid_c, float loc,
-                                              float scale, unsigned long long t_click, unsigned long long t_conv, float mu,
+                                              float scale, const adc::AuctionLaw &law, unsigned long long t_conv, float mu,
                                               float sd, long long budget, unsigned int &conv_out,
                                               unsigned long long &rev_out, unsigned long long &paid_cost)
 {
@@ -710,16 +721,17 @@ __device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint3
     paid_cost = 0ull;
     bool broke = false;
     const int jend = j0 + n;
-    for (int p = j0 >> 1; 2 * p < jend; ++p) {
-        const adc::U4 w = adc::draw(key, (uint32_t)p, adc::ST_AUCTION, kw, tick);
+    for (int q = j0 >> 2; 4 * q < jend; ++q) {
+        const adc::U4 w = adc::draw(key, (uint32_t)q, adc::ST_AUCTION, kw, tick);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = 2 * p + h;
+        for (int h = 0; h < 4; ++h) {
+            const int j = 4 * q + h;
             if (j < j0 || j >= jend) continue;
-            const int comp = adc::laplace_cents(h ? w.z : w.x, loc, scale);
+            bool click_bit;
+            const int comp = adc::auction_outcome(h == 0 ? w.x : h == 1 ? w.y : h == 2 ? w.z : w.w, law, loc, scale, click_bit);
             if (!(bid_c > comp)) continue;
             st.wins += 1u;
-            if (!adc::bernoulli(h ? w.w : w.y, t_click)) continue;
+            if (!click_bit) continue;
             if (MODE == 0) {
                 st.clicks += 1u;
                 st.total += (unsigned long long)comp;
@@ -828,7 +840,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
             unsigned int cv; unsigned long long rv, pc;
             const CellStat st = walk_cell<0>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
                                              param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
-                                             adc::bernoulli_threshold(param_at(v, ADC_P_BCTR, env, k)), 0ull, 0.f, 0.f, 0, cv, rv, pc);
+                                             adc::make_auction_law(param_at(v, ADC_P_BCTR, env, k)), 0ull, 0.f, 0.f, 0, cv, rv, pc);
             c_wins[k] = st.wins;
             c_first[k] = st.first;
             c_total[k] = st.total;
@@ -883,7 +895,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
                     unsigned int cv; unsigned long long rv, pc;
                     const CellStat st = walk_cell<2>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
                                                      param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
-                                                     adc::bernoulli_threshold(param_at(v, ADC_P_BCTR, env, k)),
+                                                     adc::make_auction_law(param_at(v, ADC_P_BCTR, env, k)),
                                                      adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, k)),
                                                      param_at(v, ADC_P_REV_MEAN, env, k), param_at(v, ADC_P_REV_STD, env, k), R, cv, rv, pc);
                     a_imp[k] += st.wins;
@@ -925,7 +937,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
                 unsigned int cv; unsigned long long rv, pc;
                 const CellStat st = walk_cell<1>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
                                                  param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
-                                                 adc::bernoulli_threshold(param_at(v, ADC_P_BCTR, env, k)),
+                                                 adc::make_auction_law(param_at(v, ADC_P_BCTR, env, k)),
                                                  adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, k)),
                                                  param_at(v, ADC_P_REV_MEAN, env, k), param_at(v, ADC_P_REV_STD, env, k), 0, cv, rv, pc);
                 a_imp[k] += st.wins;

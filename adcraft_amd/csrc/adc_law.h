@@ -28,7 +28,8 @@
 
 namespace adc {
 
-// IMPLICIT: call (j/2, ST_AUCTION) = {bid, click} words of auction j even (x,y) and j odd (z,w);
+// IMPLICIT: call (j/4, ST_AUCTION) = one word per auction j (x,y,z,w for j%4 = 0..3); the word decides the
+//           click AND supplies the competitor-bid uniform (interval splitting, see AuctionLaw);
 //           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
@@ -189,6 +190,55 @@ ADC_HD uint64_t bernoulli_threshold(float p)
     return (uint64_t)t;
 }
 ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < threshold; }
+
+// One word per auction.  click <=> word < T with T = round(ctr * 2^32) (as every Bernoulli here).  Inside
+// either outcome the word is still uniform on its sub-interval [0,T) or [T,2^32), so rescaling its offset d
+// to 24 bits, i24 = floor(d * 2^24 / range) computed as mulhi(d, floor(2^56 / range)), gives a uniform that is
+// independent of the click: bit 0 = sign, bits 23..1 = magnitude of the Laplace competitor bid.  (Integer
+// rescaling on purpose: a float32 product cannot carry 32 bits and correlates the sign bit with the magnitude.)
+struct AuctionLaw {
+    uint64_t t_click;      // Bernoulli threshold in [0, 2^32]
+    uint32_t m_click;      // floor(2^56 / T)            (0 if T == 0)
+    uint32_t m_noclick;    // floor(2^56 / (2^32 - T))   (0 if T == 2^32)
+};
+
+ADC_HD uint32_t rescale_multiplier(double range)
+{
+    if (!(range > 0.0)) return 0u;
+    const double m = __builtin_floor(72057594037927936.0 / range);
+    return m < 4294967295.0 ? (uint32_t)m : 4294967295u;
+}
+
+ADC_HD AuctionLaw make_auction_law(float bctr)
+{
+    AuctionLaw a;
+    a.t_click = bernoulli_threshold(bctr);
+    const double t = (double)a.t_click;
+    a.m_click = rescale_multiplier(t);
+    a.m_noclick = rescale_multiplier(4294967296.0 - t);
+    return a;
+}
+
+ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, bool &click)
+{
+    click = (uint64_t)w < a.t_click;
+    const uint32_t d = click ? w : w - (uint32_t)a.t_click;
+    uint32_t i24 = mulhi32(d, click ? a.m_click : a.m_noclick);
+    i24 = i24 < 0x00FFFFFFu ? i24 : 0x00FFFFFFu;
+    const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;      // (0,1)
+    const float e = -det_log(u);
+    const float z = (i24 & 1u) ? e : -e;
+    return money_to_cents(__builtin_fabsf(fma32(scale, z, loc)));
+}
 
 ADC_HD int32_t revenue_cents(uint32_t w, float mu, float sd)
 {

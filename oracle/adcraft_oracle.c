@@ -49,7 +49,8 @@ enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1 };
 enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT };
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
 enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
-/* IMPLICIT stream layout: call (j/2, ST_AUCTION) holds {bid, click} words of auctions j even (x,y) and j odd (z,w);
+/* IMPLICIT stream layout: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the
+ * click (word < T) and, rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome);
  * call (j, ST_CONV) holds {conversion, revenue} words (x,y) of auction j and is only consumed for a paid click. */
 #define ORC_TIMESTEPS 24
 #define ORC_VMAX (1 << 20)
@@ -174,6 +175,33 @@ ORC_API uint64_t orc_bernoulli_threshold(float p)
     if (!(t > 0.0)) return 0;
     if (t > 4294967296.0) t = 4294967296.0;
     return (uint64_t)t;
+}
+
+/* one word per auction: click <=> word < T (rng.random() <= buyside_ctr, synthetic_kw_helpers.py:73-77); the word is
+ * uniform inside either sub-interval, so d / range is a uniform independent of the click; 24 bits of it feed the
+ * competitor bid round2(|Laplace(loc, scale)|) (synthetic_kw_helpers.py:104-113): bit 0 sign, bits 23..1 magnitude. */
+static uint32_t rescale_multiplier(double range)      /* floor(2^56 / range), saturated */
+{
+    if (!(range > 0.0)) return 0u;
+    double m = floor(72057594037927936.0 / range);
+    return m < 4294967295.0 ? (uint32_t)m : 4294967295u;
+}
+ORC_API int32_t orc_auction_outcome(uint32_t w, float bctr, float loc, float scale, int32_t *click_out)
+{
+    const uint64_t T = orc_bernoulli_threshold(bctr);
+    const int click = (uint64_t)w < T;
+    const uint32_t d = click ? w : w - (uint32_t)T;
+    const uint32_t m = click ? rescale_multiplier((double)T) : rescale_multiplier(4294967296.0 - (double)T);
+    uint32_t i24 = (uint32_t)(((uint64_t)d * m) >> 32);     /* floor(d * 2^24 / range): integer, exact */
+    if (i24 > 0x00FFFFFFu) i24 = 0x00FFFFFFu;
+    const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;
+    const float e = -orc_det_logf(u);
+    const float z = (i24 & 1u) ? e : -e;
+    const float a = fabsf(fmaf(scale, z, loc));
+    float c = rintf(a * 100.0f);
+    if (!(c < 1.0e9f)) c = 1.0e9f;
+    *click_out = click;
+    return (int32_t)c;
 }
 
 /* revenue in cents: round2(max(N(mu, sd), 0.01))  (synthetic_kw_helpers.py:66-70) */
@@ -396,7 +424,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
             const int32_t n = t == 0 ? V[k] - (ORC_TIMESTEPS - 1) * stepv : stepv;
             const int32_t j0 = t == 0 ? 0 : V[k] - (ORC_TIMESTEPS - 1) * stepv + (t - 1) * stepv;
             const int64_t bid_c = orc_bid_cents(bids[base + k]);
-            const uint64_t t_click = orc_bernoulli_threshold(P(s, c, P_BCTR, env, k));
+            const uint64_t t_click = orc_bernoulli_threshold(P(s, c, P_BCTR, env, k));   /* EXPLICIT click words */
             const uint64_t t_conv = orc_bernoulli_threshold(P(s, c, P_SCTR, env, k));
             const float rev_mu = P(s, c, P_REV_MEAN, env, k), rev_sd = P(s, c, P_REV_STD, env, k);
 
@@ -409,20 +437,18 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                 /* pass 1: the auctions (impressions are not budget-limited, :86-88) */
                 int64_t click_cur = tape ? tape->cur_click : 0;
                 for (int32_t i = 0; i < n; ++i) {
-                    uint32_t wb = 0, wc = 0;                       /* bid word, click word of auction j0+i */
+                    int32_t click_bit = 0;
                     const uint32_t j = (uint32_t)(j0 + i);
                     int64_t comp;
                     if (use_tape) comp = tape->bid_cents[tape->cur_bid++];
                     else {
                         uint32_t w[4];
-                        draw(key, j >> 1, ST_AUCTION, (uint32_t)k, tick, w);
-                        wb = (j & 1u) ? w[2] : w[0];
-                        wc = (j & 1u) ? w[3] : w[1];
-                        comp = orc_laplace_cents_from_word(wb, loc, scale);
+                        draw(key, j >> 2, ST_AUCTION, (uint32_t)k, tick, w);
+                        comp = orc_auction_outcome(w[j & 3u], P(s, c, P_BCTR, env, k), loc, scale, &click_bit);
                     }
                     if (!(bid_c > comp)) continue;             /* tie loses, helpers.py:167-170 */
                     ++wins;
-                    int clicked = use_tape ? tape->click[click_cur + wins - 1] : ((uint64_t)wc < t_click);
+                    int clicked = use_tape ? tape->click[click_cur + wins - 1] : click_bit;
                     if (!clicked || broke) continue;
                     if (budget >= comp) {                      /* :97-104 */
                         budget -= comp; cell_cost += comp; ++paid;

@@ -162,3 +162,30 @@ def test_explicit_cost_law():
     assert c.min() >= 0 and c.max() <= 4.4 + 1e-6
     assert abs(c.mean() - (0.9 / 4 + 2.2)) < 0.01          # the reference's own standard: moments to 2 dp
     assert abs(c.std() - 0.15) < 0.01
+
+
+def test_auction_word_law_click_and_bid_are_independent_and_right():
+    """one word per auction (orc_auction_outcome): the click frequency is ctr, and the competitor bid has the
+    reference's law (bid_abs_laplace) both given a click and given no click."""
+    import ctypes as C
+    loc, scale, ctr = np.float32(0.55), np.float32(0.08), np.float32(0.3)
+    n = 300_000
+    click = C.c_int32()
+    comp = np.zeros(n, dtype=np.int64)
+    clicks = np.zeros(n, dtype=bool)
+    for i, w in enumerate(_words(n, 21)):
+        comp[i] = L.orc_auction_outcome(int(w), float(ctr), float(loc), float(scale), C.byref(click))
+        clicks[i] = click.value
+    assert abs(clicks.mean() - float(ctr)) < 4 * np.sqrt(0.3 * 0.7 / n)
+    ref = np.rint(rn.bid_abs_laplace(float(loc), float(scale), np.random.default_rng(22))(1, n).ravel() * 100).astype(int)
+    for sel in (clicks, ~clicks):
+        mine = comp[sel]
+        hi = int(max(mine.max(), ref.max())) + 1
+        a, b = np.bincount(mine, minlength=hi).astype(float), np.bincount(ref, minlength=hi).astype(float)
+        keep = (a + b) >= 40
+        k1, k2 = np.sqrt(b.sum() / a.sum()), np.sqrt(a.sum() / b.sum())       # two-sample chi-square, unequal sizes
+        chi2 = (((k1 * a - k2 * b)[keep] ** 2) / (a + b)[keep]).sum()
+        assert stats.chi2.sf(chi2, keep.sum() - 1) > 1e-4
+    # degenerate rates
+    assert L.orc_auction_outcome(123456789, 0.0, float(loc), float(scale), C.byref(click)) >= 0 and click.value == 0
+    assert L.orc_auction_outcome(4294967295, 1.0, float(loc), float(scale), C.byref(click)) >= 0 and click.value == 1
