@@ -169,8 +169,8 @@ struct FastShared {
     int vol[kFastBlock];
     int bid_c[kFastBlock];
     float loc[kFastBlock], scale[kFastBlock], mu[kFastBlock], sd[kFastBlock];
-    unsigned long long t_click[kFastBlock], t_conv[kFastBlock];       // Bernoulli thresholds
-    unsigned int m_click[kFastBlock], m_noclick[kFastBlock];           // AuctionLaw rescale multipliers
+    unsigned long long t_conv[kFastBlock];                              // Bernoulli threshold of the conversion
+    unsigned int t_lo[kFastBlock], always[kFastBlock], m_click[kFastBlock], m_noclick[kFastBlock];   // AuctionLaw
     unsigned int a_imp[kFastBlock], a_clk[kFastBlock], a_conv[kFastBlock];
     unsigned long long a_cost[kFastBlock], a_rev[kFastBlock];
     unsigned int queue[kFastBlock / kWave][kQueueCap];
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         sh.mu[tid] = param_at(v, ADC_P_REV_MEAN, env, k);
         sh.sd[tid] = param_at(v, ADC_P_REV_STD, env, k);
         const adc::AuctionLaw law = adc::make_auction_law(bctr);
-        sh.t_click[tid] = law.t_click;
+        sh.t_lo[tid] = law.t_lo;
+        sh.always[tid] = law.always;
         sh.m_click[tid] = law.m_click;
         sh.m_noclick[tid] = law.m_noclick;
         sh.t_conv[tid] = adc::bernoulli_threshold(sctr);
@@ -245,7 +246,6 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
     // full wavefronts instead of on the ~20 % of lanes that happen to convert.
     unsigned int *const ring = sh.queue[wv];
     unsigned int qhead = 0, qtail = 0;
-    const unsigned long long lt = lanemask_lt();
     const uint32_t kw_base = (uint32_t)(tile * kFastBlock);
 
     auto resolve_click = [&](unsigned int pos) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         }
         const int bid_c = sh.bid_c[u];
         const float loc = sh.loc[u], scale = sh.scale[u];
-        const adc::AuctionLaw law{sh.t_click[u], sh.m_click[u], sh.m_noclick[u]};
+        const adc::AuctionLaw law{sh.t_lo[u], sh.always[u], sh.m_click[u], sh.m_noclick[u]};
         const uint32_t kw = kw_base + (uint32_t)u;
         const unsigned int tag = (unsigned int)u << 24;
         unsigned int imp = 0, clk = 0;
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
             clk += (unsigned int)click;
             cost += click ? (unsigned long long)comp : 0ull;               // 2nd price = the competitor's bid
             const unsigned long long m = __ballot(click);
-            if (click) ring[(qtail + __popcll(m & lt)) & (kQueueCap - 1)] = tag | (unsigned int)j;
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            if (click) ring[(qtail + rank) & (kQueueCap - 1)] = tag | (unsigned int)j;
             qtail += __popcll(m);
         };
         auto drain = [&]() {

@@ -197,25 +197,30 @@ ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < thr
 // independent of the click: bit 0 = sign, bits 23..1 = magnitude of the Laplace competitor bid.  (Integer
 // rescaling on purpose: a float32 product cannot carry 32 bits and correlates the sign bit with the magnitude.)
 struct AuctionLaw {
-    uint64_t t_click;      // Bernoulli threshold in [0, 2^32]
+    uint32_t t_lo;         // low 32 bits of the Bernoulli threshold T in [0, 2^32]
+    uint32_t always;       // T == 2^32 (ctr == 1): every word clicks
     uint32_t m_click;      // floor(2^56 / T)            (0 if T == 0)
     uint32_t m_noclick;    // floor(2^56 / (2^32 - T))   (0 if T == 2^32)
 };
 
-ADC_HD uint32_t rescale_multiplier(double range)
+// floor(2^56 / range) in float32 (one correctly rounded division; 24 good bits are plenty: the map d -> i24
+// stays monotone and each i24 value keeps its share of words to within one word), saturated to 32 bits
+ADC_HD uint32_t rescale_multiplier(uint64_t range)
 {
-    if (!(range > 0.0)) return 0u;
-    const double m = __builtin_floor(72057594037927936.0 / range);
-    return m < 4294967295.0 ? (uint32_t)m : 4294967295u;
+    if (range == 0) return 0u;
+    float m = __builtin_floorf(72057594037927936.0f / (float)range);
+    m = m < 4294967040.0f ? m : 4294967040.0f;
+    return (uint32_t)m;
 }
 
 ADC_HD AuctionLaw make_auction_law(float bctr)
 {
+    const uint64_t t = bernoulli_threshold(bctr);
     AuctionLaw a;
-    a.t_click = bernoulli_threshold(bctr);
-    const double t = (double)a.t_click;
+    a.t_lo = (uint32_t)t;
+    a.always = t >> 32 ? 1u : 0u;
     a.m_click = rescale_multiplier(t);
-    a.m_noclick = rescale_multiplier(4294967296.0 - t);
+    a.m_noclick = rescale_multiplier(4294967296ull - t);
     return a;
 }
 
@@ -230,8 +235,8 @@ ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 
 ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, bool &click)
 {
-    click = (uint64_t)w < a.t_click;
-    const uint32_t d = click ? w : w - (uint32_t)a.t_click;
+    click = (w < a.t_lo) | (a.always != 0u);
+    const uint32_t d = click ? w : w - a.t_lo;
     uint32_t i24 = mulhi32(d, click ? a.m_click : a.m_noclick);
     i24 = i24 < 0x00FFFFFFu ? i24 : 0x00FFFFFFu;
     const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;      // (0,1)

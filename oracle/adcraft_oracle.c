@@ -180,19 +180,20 @@ ORC_API uint64_t orc_bernoulli_threshold(float p)
 /* one word per auction: click <=> word < T (rng.random() <= buyside_ctr, synthetic_kw_helpers.py:73-77); the word is
  * uniform inside either sub-interval, so d / range is a uniform independent of the click; 24 bits of it feed the
  * competitor bid round2(|Laplace(loc, scale)|) (synthetic_kw_helpers.py:104-113): bit 0 sign, bits 23..1 magnitude. */
-static uint32_t rescale_multiplier(double range)      /* floor(2^56 / range), saturated */
+static uint32_t rescale_multiplier(uint64_t range)      /* floor(2^56 / range) in float32, saturated */
 {
-    if (!(range > 0.0)) return 0u;
-    double m = floor(72057594037927936.0 / range);
-    return m < 4294967295.0 ? (uint32_t)m : 4294967295u;
+    if (range == 0) return 0u;
+    float m = floorf(72057594037927936.0f / (float)range);
+    if (!(m < 4294967040.0f)) m = 4294967040.0f;
+    return (uint32_t)m;
 }
 ORC_API int32_t orc_auction_outcome(uint32_t w, float bctr, float loc, float scale, int32_t *click_out)
 {
     const uint64_t T = orc_bernoulli_threshold(bctr);
     const int click = (uint64_t)w < T;
     const uint32_t d = click ? w : w - (uint32_t)T;
-    const uint32_t m = click ? rescale_multiplier((double)T) : rescale_multiplier(4294967296.0 - (double)T);
-    uint32_t i24 = (uint32_t)(((uint64_t)d * m) >> 32);     /* floor(d * 2^24 / range): integer, exact */
+    const uint32_t m = click ? rescale_multiplier(T) : rescale_multiplier(4294967296ull - T);
+    uint32_t i24 = (uint32_t)(((uint64_t)d * m) >> 32);     /* ~ floor(d * 2^24 / range): integer multiply */
     if (i24 > 0x00FFFFFFu) i24 = 0x00FFFFFFu;
     const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;
     const float e = -orc_det_logf(u);

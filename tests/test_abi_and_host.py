@@ -233,3 +233,16 @@ def test_flatten_matches_reference(golden):
     obs = {k: np.array(v) for k, v in g["obs"].items()}
     assert utils.flatten_dict_array(obs).tolist() == g["flat"]
     assert list(utils.FLAT_OBS_KEYS) == g["key_order"]
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """the boundary is a C ABI: the header compiles as C99 and a C program links against the library"""
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "adcraft_engine.h")])
+    exe = str(tmp_path / "c_abi_minimal")
+    libdir = os.path.dirname(_ffi.library_path())
+    _ffi.lib()
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", inc, os.path.join(ROOT, "examples", "c_abi_minimal.c"),
+                           "-L", libdir, "-ladcraft_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    assert os.path.exists(exe)

@@ -126,3 +126,16 @@ def test_engine_checkpoint_resume(torch_cuda):
             assert np.array_equal(x[k], y[k]), k
     a.close()
     b.close()
+
+
+def test_c_program_runs_against_the_library(tmp_path):
+    import os
+    import subprocess
+    from adcraft_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_minimal")
+    libdir = os.path.dirname(_ffi.library_path())
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_minimal.c"),
+                           "-L", libdir, "-ladcraft_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.check_output([exe], text=True)
+    assert out.strip().endswith("ok") and "step 2 env 3" in out and "terminated" in out
