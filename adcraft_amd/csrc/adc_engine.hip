@@ -162,23 +162,27 @@ __device__ __forceinline__ void drift_keyword(const View &v, uint64_t key, uint3
 // -------------------------------------------------------------------------------------------------
 // FAST PASS (IMPLICIT, engine stream, budget ignored)
 // -------------------------------------------------------------------------------------------------
-constexpr int kQueueCap = 256;    // per-wave ring of deferred paid clicks (entries), power of two
+constexpr int kQueueCap = 128;    // per-wave ring of deferred paid clicks (entries), power of two; drained whenever 64 wait
 
+// 72 B per keyword + the rings = exactly 20 KiB, so 8 workgroups (32 waves) fit a CU's 160 KiB of LDS
 struct FastShared {
     int off[kFastBlock];            // exclusive prefix of chunk counts
     int vol[kFastBlock];
     int bid_c[kFastBlock];
     float loc[kFastBlock], scale[kFastBlock], mu[kFastBlock], sd[kFastBlock];
-    unsigned long long t_conv[kFastBlock];                              // Bernoulli threshold of the conversion
-    unsigned int t_lo[kFastBlock], always[kFastBlock], m_click[kFastBlock], m_noclick[kFastBlock];   // AuctionLaw
+    unsigned int t_click[kFastBlock], m_click[kFastBlock], m_noclick[kFastBlock];     // AuctionLaw
+    unsigned int t_conv[kFastBlock];                                                    // saturated conversion threshold
     unsigned int a_imp[kFastBlock], a_clk[kFastBlock], a_conv[kFastBlock];
     unsigned long long a_cost[kFastBlock], a_rev[kFastBlock];
-    unsigned int queue[kFastBlock / kWave][kQueueCap];
-    int wave_tot[kFastBlock / kWave];
-    long long red[2][kFastBlock / kWave];
+    union {
+        unsigned int queue[kFastBlock / kWave][kQueueCap];     // phase 2
+        int wave_tot[kFastBlock / kWave];                      // phase 1 (before the rings are used)
+        long long red[2][kFastBlock / kWave];                  // phase 3 (after they are drained)
+    };
 };
+static_assert(sizeof(FastShared) <= 20480, "FastShared must stay within 20 KiB for 8 workgroups per CU");
 
-__global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const float *__restrict__ bids)
+__global__ __launch_bounds__(kFastBlock, 8) void k_step_implicit_fast(View v, const float *__restrict__ bids)
 {
     __shared__ FastShared sh;
     const int tiles = (v.K + kFastBlock - 1) / kFastBlock;
@@ -211,11 +215,10 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         sh.mu[tid] = param_at(v, ADC_P_REV_MEAN, env, k);
         sh.sd[tid] = param_at(v, ADC_P_REV_STD, env, k);
         const adc::AuctionLaw law = adc::make_auction_law(bctr);
-        sh.t_lo[tid] = law.t_lo;
-        sh.always[tid] = law.always;
+        sh.t_click[tid] = law.t32;
         sh.m_click[tid] = law.m_click;
         sh.m_noclick[tid] = law.m_noclick;
-        sh.t_conv[tid] = adc::bernoulli_threshold(sctr);
+        sh.t_conv[tid] = adc::saturate_threshold(adc::bernoulli_threshold(sctr));
         sh.bid_c[tid] = (int)adc::bid_to_cents(bids[(size_t)env * v.K + k]);
         const adc::U4 w = adc::draw(key, 0u, adc::ST_VOL, (uint32_t)k, tick);
         V = adc::volume_from_word(w.x, vol_mean, vol_std);
@@ -239,8 +242,8 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
 
     // ---- phase 2: chunks of kChunk auctions, dealt round-robin ----------------------------------
     // Control flow is wave-uniform (idle lanes carry n = 0) so that the deferred-click ring below can
-    // be maintained with ballots.  Stage A (every auction): one Philox call per PAIR of auctions ->
-    // competitor bid, 2nd-price clearing, click.  Stage B (paid clicks only, ~1/4 of auctions): the
+    // be maintained with ballots.  Stage A (every auction): one Philox call per FOUR auctions (one word
+    // each) -> click bit + competitor bid, 2nd-price clearing.  Stage B (paid clicks only, ~1/4 of auctions): the
     // click's (keyword, auction) is pushed to a per-wave LDS ring; whenever 64 are waiting, all 64
     // lanes draw the conversion/revenue call together - so the expensive normal-quantile runs on
     // full wavefronts instead of on the ~20 % of lanes that happen to convert.
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         const unsigned int ent = ring[pos & (kQueueCap - 1)];
         const unsigned int uu = ent >> 24;
         const adc::U4 w2 = adc::draw(key, ent & 0x00FFFFFFu, adc::ST_CONV, kw_base + uu, tick);
-        if (adc::bernoulli(w2.x, sh.t_conv[uu])) {
+        if (adc::bernoulli32(w2.x, sh.t_conv[uu])) {
             const int rv = adc::revenue_cents(w2.y, sh.mu[uu], sh.sd[uu]);
             atomicAdd(&sh.a_conv[uu], 1u);
             atomicAdd(&sh.a_rev[uu], (unsigned long long)rv);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
         }
         const int bid_c = sh.bid_c[u];
         const float loc = sh.loc[u], scale = sh.scale[u];
-        const adc::AuctionLaw law{sh.t_lo[u], sh.always[u], sh.m_click[u], sh.m_noclick[u]};
+        const adc::AuctionLaw law{sh.t_click[u], sh.m_click[u], sh.m_noclick[u]};
         const uint32_t kw = kw_base + (uint32_t)u;
         const unsigned int tag = (unsigned int)u << 24;
         unsigned int imp = 0, clk = 0;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
             qtail += __popcll(m);
         };
         auto drain = [&]() {
-            while (qtail - qhead >= (unsigned int)kWave) {      // <= 63 + 128 entries can be waiting (ring holds 256)
+            while (qtail - qhead >= (unsigned int)kWave) {      // checked after every push: <= 63 + 64 entries wait (ring holds 128)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 resolve_click(qhead + lane);
@@ -303,9 +306,11 @@ __global__ __launch_bounds__(kFastBlock) void k_step_implicit_fast(View v, const
             if (!__any(i < n)) break;
             const adc::U4 w = adc::draw(key, (uint32_t)(j0 + i) >> 2, adc::ST_AUCTION, kw, tick);
             auction(w.x, j0 + i, i < n);
+            drain();
             auction(w.y, j0 + i + 1, i + 1 < n);
             drain();
             auction(w.z, j0 + i + 2, i + 2 < n);
+            drain();
             auction(w.w, j0 + i + 3, i + 3 < n);
             drain();
         }

@@ -190,6 +190,10 @@ ADC_HD uint64_t bernoulli_threshold(float p)
     return (uint64_t)t;
 }
 ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < threshold; }
+// the same test with the threshold saturated to 32 bits: 0xFFFFFFFF can only come from T = 2^32 (p = 1; the
+// largest float32 below 1 gives T = 2^32 - 256), so it encodes "always"
+ADC_HD uint32_t saturate_threshold(uint64_t t) { return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t; }
+ADC_HD bool bernoulli32(uint32_t w, uint32_t t32) { return (w < t32) | (t32 == 0xFFFFFFFFu); }
 
 // One word per auction.  click <=> word < T with T = round(ctr * 2^32) (as every Bernoulli here).  Inside
 // either outcome the word is still uniform on its sub-interval [0,T) or [T,2^32), so rescaling its offset d
@@ -197,8 +201,7 @@ ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < thr
 // independent of the click: bit 0 = sign, bits 23..1 = magnitude of the Laplace competitor bid.  (Integer
 // rescaling on purpose: a float32 product cannot carry 32 bits and correlates the sign bit with the magnitude.)
 struct AuctionLaw {
-    uint32_t t_lo;         // low 32 bits of the Bernoulli threshold T in [0, 2^32]
-    uint32_t always;       // T == 2^32 (ctr == 1): every word clicks
+    uint32_t t32;          // click threshold T saturated to 32 bits (0xFFFFFFFF <=> T = 2^32: every word clicks)
     uint32_t m_click;      // floor(2^56 / T)            (0 if T == 0)
     uint32_t m_noclick;    // floor(2^56 / (2^32 - T))   (0 if T == 2^32)
 };
@@ -217,8 +220,7 @@ ADC_HD AuctionLaw make_auction_law(float bctr)
 {
     const uint64_t t = bernoulli_threshold(bctr);
     AuctionLaw a;
-    a.t_lo = (uint32_t)t;
-    a.always = t >> 32 ? 1u : 0u;
+    a.t32 = saturate_threshold(t);
     a.m_click = rescale_multiplier(t);
     a.m_noclick = rescale_multiplier(4294967296ull - t);
     return a;
@@ -235,8 +237,8 @@ ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 
 ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, bool &click)
 {
-    click = (w < a.t_lo) | (a.always != 0u);
-    const uint32_t d = click ? w : w - a.t_lo;
+    click = bernoulli32(w, a.t32);
+    const uint32_t d = click ? w : w - a.t32;
     uint32_t i24 = mulhi32(d, click ? a.m_click : a.m_noclick);
     i24 = i24 < 0x00FFFFFFu ? i24 : 0x00FFFFFFu;
     const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;      // (0,1)
