@@ -144,6 +144,15 @@ __device__ __forceinline__ int wave_scan_i32(int x)
     return x;
 }
 
+// log table of the auction law (adc_law.h neg_log_u24), one copy per device, filled at engine creation
+__device__ adc::LogTableEntry g_log_table[adc::kLogTableIntervals];
+
+__global__ void k_build_log_table()
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < adc::kLogTableIntervals) g_log_table[i] = adc::log_table_entry(i);
+}
+
 // pending drift of one keyword (adcraft/gymnasium_kw_env.py:132-158); `tick_of_draw` = tick of the
 // step whose update_keywords() this is
 __device__ __forceinline__ void drift_keyword(const View &v, uint64_t key, uint32_t tick_of_draw, int k,
@@ -164,7 +173,7 @@ __device__ __forceinline__ void drift_keyword(const View &v, uint64_t key, uint3
 // -------------------------------------------------------------------------------------------------
 constexpr int kQueueCap = 128;    // per-wave ring of deferred paid clicks (entries), power of two; drained whenever 64 wait
 
-// 72 B per keyword + the rings = exactly 20 KiB, so 8 workgroups (32 waves) fit a CU's 160 KiB of LDS
+// 72 B per keyword + the 2 KiB log table + the rings = 22 KiB: 7 workgroups (28 waves) per CU's 160 KiB of LDS
 struct FastShared {
     int off[kFastBlock];            // exclusive prefix of chunk counts
     int vol[kFastBlock];
@@ -174,15 +183,17 @@ struct FastShared {
     unsigned int t_conv[kFastBlock];                                                    // saturated conversion threshold
     unsigned int a_imp[kFastBlock], a_clk[kFastBlock], a_conv[kFastBlock];
     unsigned long long a_cost[kFastBlock], a_rev[kFastBlock];
+    adc::LogTableEntry logtab[adc::kLogTableIntervals];                                 // copy of g_log_table (kFastBlock == intervals)
     union {
         unsigned int queue[kFastBlock / kWave][kQueueCap];     // phase 2
         int wave_tot[kFastBlock / kWave];                      // phase 1 (before the rings are used)
         long long red[2][kFastBlock / kWave];                  // phase 3 (after they are drained)
     };
 };
-static_assert(sizeof(FastShared) <= 20480, "FastShared must stay within 20 KiB for 8 workgroups per CU");
+static_assert(kFastBlock == adc::kLogTableIntervals, "one table entry per lane is copied in phase 1");
+static_assert(sizeof(FastShared) <= 163840 / 7, "FastShared must allow 7 workgroups per CU");
 
-__global__ __launch_bounds__(kFastBlock, 8) void k_step_implicit_fast(View v, const float *__restrict__ bids)
+__global__ __launch_bounds__(kFastBlock, 7) void k_step_implicit_fast(View v, const float *__restrict__ bids)
 {
     __shared__ FastShared sh;
     const int tiles = (v.K + kFastBlock - 1) / kFastBlock;
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(kFastBlock, 8) void k_step_implicit_fast(View v, co
         const adc::U4 w = adc::draw(key, 0u, adc::ST_VOL, (uint32_t)k, tick);
         V = adc::volume_from_word(w.x, vol_mean, vol_std);
     }
+    sh.logtab[tid] = g_log_table[tid];
     sh.vol[tid] = V;
     sh.a_imp[tid] = sh.a_clk[tid] = sh.a_conv[tid] = 0u;
     sh.a_cost[tid] = sh.a_rev[tid] = 0ull;
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(kFastBlock, 8) void k_step_implicit_fast(View v, co
         // one auction: 2nd-price clearing against the sampled competitor bid, click, deferred conversion
         auto auction = [&](uint32_t word, int j, bool active) {
             bool click_bit;
-            const int comp = adc::auction_outcome(word, law, loc, scale, click_bit);
+            const int comp = adc::auction_outcome(word, law, loc, scale, sh.logtab, click_bit);
             const bool win = active && bid_c > comp;                       // tie loses (helpers.py:167-170)
             const bool click = win && click_bit;
             imp += (unsigned int)win;
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
                             else {
                                 const adc::U4 w = adc::draw(key, j >> 2, adc::ST_AUCTION, (uint32_t)k, tick);
                                 const uint32_t word = (j & 3u) == 0 ? w.x : (j & 3u) == 1 ? w.y : (j & 3u) == 2 ? w.z : w.w;
-                                comp = adc::auction_outcome(word, law, loc, scale, click_bit);
+                                comp = adc::auction_outcome(word, law, loc, scale, g_log_table, click_bit);
                             }
                         }
                         const bool win = act && bid_c > comp;
@@ -734,7 +746,7 @@ __device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint3
             const int j = 4 * q + h;
             if (j < j0 || j >= jend) continue;
             bool click_bit;
-            const int comp = adc::auction_outcome(h == 0 ? w.x : h == 1 ? w.y : h == 2 ? w.z : w.w, law, loc, scale, click_bit);
+            const int comp = adc::auction_outcome(h == 0 ? w.x : h == 1 ? w.y : h == 2 ? w.z : w.w, law, loc, scale, g_log_table, click_bit);
             if (!(bid_c > comp)) continue;
             st.wins += 1u;
             if (!click_bit) continue;
@@ -1477,6 +1489,7 @@ ADC_EXPORT int adc_engine_create(const adc_config *cfg, adc_engine **out)
     A(v.metric_profit, K); A(v.metric_scalars, 8); A(v.metric_env, 4 * N); A(v.metric_kw, NK);
     A(e->d_bids, NK); A(e->d_budget, N);
 #undef A
+    hipLaunchKernelGGL(k_build_log_table, dim3(1), dim3(256), 0, e->stream);
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, v, cfg->seed, cfg->env_id_base);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
         return bail(fail(ADC_EHIP, "engine initialisation kernel failed (is this a gfx950 device?)"));

@@ -195,6 +195,32 @@ ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < thr
 ADC_HD uint32_t saturate_threshold(uint64_t t) { return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t; }
 ADC_HD bool bernoulli32(uint32_t w, uint32_t t32) { return (w < t32) | (t32 == 0xFFFFFFFFu); }
 
+// -log(u) for u = w24 / 2^24, w24 odd in [1, 2^24): exponent from the float32 bits, mantissa through a
+// 256-interval table of det_log on [1,2) with linear interpolation (error < 4e-6, i.e. < 4e-5 cent of a typical
+// bid - far below the cent rounding).  tab[i] = {det_log(1 + i/256), (det_log(1 + (i+1)/256) - det_log(1 + i/256)) * 2^-15}: the table
+// itself is built with det_log, so host and device hold the same bits.
+struct LogTableEntry { float value, slope; };
+constexpr int kLogTableIntervals = 256;
+
+ADC_HD LogTableEntry log_table_entry(int i)
+{
+    const float a = det_log(1.0f + (float)i * 0.00390625f);
+    const float b = det_log(1.0f + (float)(i + 1) * 0.00390625f);
+    return LogTableEntry{a, (b - a) * 3.0517578125e-05f};
+}
+
+ADC_HD float neg_log_u24(uint32_t w24, const LogTableEntry *tab)
+{
+    const uint32_t bits = float_to_bits((float)w24);                 // exact: w24 < 2^24
+    const float ef = (float)((int)(bits >> 23) - 151);              // exponent of u = w24 * 2^-24, in [-24, -1]
+    const uint32_t mant = bits & 0x007FFFFFu;
+    const LogTableEntry t = tab[mant >> 15];
+    float r = fma32(t.slope, (float)(mant & 0x7FFFu), t.value);
+    r = fma32(ef, -2.12194440e-4f, r);
+    r = fma32(ef, 0.693359375f, r);
+    return -r;
+}
+
 // One word per auction.  click <=> word < T with T = round(ctr * 2^32) (as every Bernoulli here).  Inside
 // either outcome the word is still uniform on its sub-interval [0,T) or [T,2^32), so rescaling its offset d
 // to 24 bits, i24 = floor(d * 2^24 / range) computed as mulhi(d, floor(2^56 / range)), gives a uniform that is
@@ -235,14 +261,13 @@ ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 
-ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, bool &click)
+ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, const LogTableEntry *tab, bool &click)
 {
     click = bernoulli32(w, a.t32);
     const uint32_t d = click ? w : w - a.t32;
     uint32_t i24 = mulhi32(d, click ? a.m_click : a.m_noclick);
     i24 = i24 < 0x00FFFFFFu ? i24 : 0x00FFFFFFu;
-    const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;      // (0,1)
-    const float e = -det_log(u);
+    const float e = neg_log_u24(i24 | 1u, tab);                  // u = (2*mag + 1) / 2^24 in (0,1), mag = i24 >> 1
     const float z = (i24 & 1u) ? e : -e;
     return money_to_cents(__builtin_fabsf(fma32(scale, z, loc)));
 }

@@ -180,6 +180,29 @@ ORC_API uint64_t orc_bernoulli_threshold(float p)
 /* one word per auction: click <=> word < T (rng.random() <= buyside_ctr, synthetic_kw_helpers.py:73-77); the word is
  * uniform inside either sub-interval, so d / range is a uniform independent of the click; 24 bits of it feed the
  * competitor bid round2(|Laplace(loc, scale)|) (synthetic_kw_helpers.py:104-113): bit 0 sign, bits 23..1 magnitude. */
+/* -log(u), u = w24 / 2^24 (w24 odd): exponent from the float bits, mantissa through a 256-interval table of
+ * orc_det_logf on [1,2) with linear interpolation; the table is built from orc_det_logf itself */
+static float g_log_value[257], g_log_slope[256];
+static int g_log_ready = 0;
+static void build_log_table(void)
+{
+    for (int i = 0; i <= 256; ++i) g_log_value[i] = orc_det_logf(1.0f + (float)i * 0.00390625f);
+    for (int i = 0; i < 256; ++i) g_log_slope[i] = (g_log_value[i + 1] - g_log_value[i]) * 3.0517578125e-05f;
+    g_log_ready = 1;
+}
+ORC_API float orc_neg_log_u24(uint32_t w24)
+{
+    if (!g_log_ready) build_log_table();
+    const uint32_t bits = as_u32((float)w24);
+    const float ef = (float)((int)(bits >> 23) - 151);
+    const uint32_t mant = bits & 0x007FFFFFu;
+    const uint32_t i = mant >> 15;
+    float r = fmaf(g_log_slope[i], (float)(mant & 0x7FFFu), g_log_value[i]);
+    r = fmaf(ef, -2.12194440e-4f, r);
+    r = fmaf(ef, 0.693359375f, r);
+    return -r;
+}
+
 static uint32_t rescale_multiplier(uint64_t range)      /* floor(2^56 / range) in float32, saturated */
 {
     if (range == 0) return 0u;
@@ -195,8 +218,7 @@ ORC_API int32_t orc_auction_outcome(uint32_t w, float bctr, float loc, float sca
     const uint32_t m = click ? rescale_multiplier(T) : rescale_multiplier(4294967296ull - T);
     uint32_t i24 = (uint32_t)(((uint64_t)d * m) >> 32);     /* ~ floor(d * 2^24 / range): integer multiply */
     if (i24 > 0x00FFFFFFu) i24 = 0x00FFFFFFu;
-    const float u = ((float)(i24 >> 1) + 0.5f) * 1.1920928955078125e-07f;
-    const float e = -orc_det_logf(u);
+    const float e = orc_neg_log_u24(i24 | 1u);                  /* u = (2*mag + 1) / 2^24 */
     const float z = (i24 & 1u) ? e : -e;
     const float a = fabsf(fmaf(scale, z, loc));
     float c = rintf(a * 100.0f);
@@ -580,6 +602,7 @@ ORC_API int32_t orc_step(const orc_config *c, orc_state *s, const float *bids, c
 {
     if (!c || !s || !bids || !budget || !o) return -1;
     if (c->num_envs <= 0 || c->num_keywords <= 0) return -1;
+    if (!g_log_ready) build_log_table();
     if (tape || c->threads <= 1) {
         for (int e = 0; e < c->num_envs; ++e)
             step_env(c, s, e, bids, budget[e], tape, o);
