@@ -349,6 +349,7 @@ __global__ __launch_bounds__(kFastBlock, 7) void k_step_implicit_fast(View v, co
         v.conv[o] = (int)sh.a_conv[tid];
         v.cost[o] = (float)my_cost / 100.0f;
         v.rev[o] = (float)r / 100.0f;
+        if (v.metrics_on) v.metric_kw[o] += my_profit;      // corrected by k_step_exact_rows if it re-runs this env
     }
     my_cost = wave_sum_i64(my_cost);
     my_profit = wave_sum_i64(my_profit);
@@ -974,6 +975,11 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
     for (int k = tid; k < K; k += kRowsBlock) {
         const size_t o = (size_t)env * K + k;
         const long long c = (long long)a_cost[k], r = (long long)a_rev[k];
+        if (v.metrics_on) {
+            long long old = 0;          // what the (discarded) fast pass added for this keyword, if it ran
+            if (!hinted) old = (long long)__builtin_rintf(v.rev[o] * 100.0f) - (long long)__builtin_rintf(v.cost[o] * 100.0f);
+            v.metric_kw[o] += (r - c) - old;
+        }
         v.imp[o] = (int)a_imp[k];
         v.clk[o] = (int)a_clk[k];
         v.conv[o] = (int)a_conv[k];
@@ -1390,7 +1396,7 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
     }
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(mark[2], e->stream));
-    if (v.metrics_on) {
+    if (v.metrics_on && !(implicit && K <= kRowsMaxK)) {      // the IMPLICIT fast / row kernels accumulate in their output phase
         const size_t nk = (size_t)N * K;
         hipLaunchKernelGGL(k_metric_accumulate, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, e->stream, v);
         HIP_TRY(hipGetLastError());

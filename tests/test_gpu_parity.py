@@ -375,3 +375,23 @@ def test_exact_pass_sparse_and_large_cells(amd):
     _run_vs_oracle(amd, 3, 200, planes, steps=3, budget=2.0)
     planes = H.implicit_params(2, 24, seed=44, mean_volume=2500)        # cells of ~100 auctions
     _run_vs_oracle(amd, 2, 24, planes, steps=2, budget=700.0)
+
+
+def test_metric_accumulators_with_hinted_exact_pass(amd):
+    """metric sums stay exact when envs alternate between fast pass, re-run by the row kernel, and hinted steps"""
+    N, K = 6, 300
+    planes = H.implicit_params(N, K, seed=33)
+    e = amd.StepEngine(N, K, seed=8)
+    e.set_all_params(planes)
+    e.reset()
+    e.metrics_enable(True)
+    e.metrics_reset()
+    prof = np.zeros(K, dtype=np.int64)
+    rng = np.random.default_rng(1)
+    for budget in (1e9, 50.0, 50.0, 1e9, 1e9, 20.0):
+        out = e.step(rng.uniform(0.3, 1.0, (N, K)).astype(np.float32), budget)
+        cents = np.rint(out["revenue"].astype(np.float64) * 100) - np.rint(out["cost"].astype(np.float64) * 100)
+        prof += cents.sum(axis=0).astype(np.int64)
+    kp, sc = e.metrics_read()
+    assert np.array_equal(kp, prof) and sc[1] == 6 * N
+    e.close()
