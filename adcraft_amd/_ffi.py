@@ -84,6 +84,8 @@ def lib():
         "adc_engine_synchronize": ([vp], C.c_int),
         "adc_engine_step_replay": ([vp, vp, vp, C.POINTER(Tape), C.POINTER(StepOut)], C.c_int),
         "adc_engine_update_keywords": ([vp], C.c_int),
+        "adc_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),
+        "adc_host_free": ([vp], None),
         "adc_engine_device_buffer": ([vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)], C.c_int),
         "adc_engine_stream": ([vp, C.POINTER(vp)], C.c_int),
         "adc_engine_sample_actions": ([vp, f32, f32, f32], C.c_int),

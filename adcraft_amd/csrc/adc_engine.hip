@@ -1740,6 +1740,22 @@ ADC_EXPORT int adc_engine_update_keywords(adc_engine *e)
     return ADC_OK;
 }
 
+ADC_EXPORT int adc_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(ADC_EINVAL, "out is NULL");
+    *out = nullptr;
+    void *p = nullptr;
+    hipError_t err = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (err != hipSuccess) return fail(ADC_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(err));
+    *out = p;
+    return ADC_OK;
+}
+
+ADC_EXPORT void adc_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 ADC_EXPORT int adc_engine_device_buffer(adc_engine *e, int buffer_id, void **dptr, size_t *bytes)
 {
     ENGINE_GUARD(e);

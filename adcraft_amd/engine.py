@@ -34,14 +34,32 @@ class StepEngine:
         check(self._lib.adc_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h
         N, K = self.num_envs, self.num_keywords
-        self.out = {name: np.zeros((N, K) if per_kw else (N,), dtype=dt) for name, dt, per_kw in _OUT_SPEC}
+        # step I/O buffers live in page-locked host memory: observations DMA straight into these numpy arrays
+        self._pinned = []
+        self.out = {name: self._pinned_array((N, K) if per_kw else (N,), dt) for name, dt, per_kw in _OUT_SPEC}
         self._out = _ffi.StepOut(*(self.out[name].ctypes.data for name, _, _ in _OUT_SPEC))
+        self._bids_stage = self._pinned_array((N, K), np.float32)
+        self._budget_stage = self._pinned_array((N,), np.float32)
+
+    def _pinned_array(self, shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(self._lib.adc_host_alloc(max(nbytes, 1), C.byref(p)))
+        self._pinned.append(p.value)
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        a[...] = 0
+        return a
 
     # ---- lifecycle
     def close(self):
         if self._h is not None:
             self._lib.adc_engine_destroy(self._h)
             self._h = None
+            self.out, self._bids_stage, self._budget_stage = {}, None, None      # drop views before freeing
+            for p in self._pinned:
+                self._lib.adc_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -112,9 +130,9 @@ class StepEngine:
 
     # ---- the hot path
     def _actions(self, bids, budget):
-        b = np.ascontiguousarray(np.broadcast_to(np.asarray(bids, dtype=np.float32), (self.num_envs, self.num_keywords)))
-        g = np.ascontiguousarray(np.broadcast_to(np.asarray(budget, dtype=np.float32), (self.num_envs,)))
-        return b, g
+        self._bids_stage[...] = np.asarray(bids, dtype=np.float32).reshape(-1, self.num_keywords) if np.ndim(bids) else bids
+        self._budget_stage[...] = budget
+        return self._bids_stage, self._budget_stage
 
     def step(self, bids, budget, copy=True):
         """host in / host out, synchronous.  Returns dict of numpy arrays (views of reused buffers if copy=False)."""

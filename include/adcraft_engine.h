@@ -179,6 +179,11 @@ int adc_engine_step_replay(adc_engine *e, const float *bids_nk, const float *bud
 /* BiddingSimulation.update_keywords() called directly (gymnasium_kw_env.py:114-158) */
 int adc_engine_update_keywords(adc_engine *e);
 
+/* page-locked host memory for step I/O buffers (DMA straight to/from the caller's arrays instead of staged
+ * pageable copies); plain malloc-style ownership: free with adc_host_free */
+int adc_host_alloc(size_t bytes, void **out);
+void adc_host_free(void *p);
+
 /* ---- device-resident access ---------------------------------------------------------------------- */
 int adc_engine_device_buffer(adc_engine *e, int buffer_id, void **dptr, size_t *bytes);
 int adc_engine_stream(adc_engine *e, void **hip_stream);
