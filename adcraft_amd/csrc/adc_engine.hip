@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kFastBlock, 7) void k_step_implicit_fast(View v, co
         const unsigned int uu = ent >> 24;
         const adc::U4 w2 = adc::draw(key, ent & 0x00FFFFFFu, adc::ST_CONV, kw_base + uu, tick);
         if (adc::bernoulli32(w2.x, sh.t_conv[uu])) {
-            const int rv = adc::revenue_cents(w2.y, sh.mu[uu], sh.sd[uu]);
+            const int rv = adc::revenue_cents_bm(w2.y, w2.z, sh.mu[uu], sh.sd[uu], sh.logtab);
             atomicAdd(&sh.a_conv[uu], 1u);
             atomicAdd(&sh.a_rev[uu], (unsigned long long)rv);
         }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
                             else {
                                 const adc::U4 w2 = adc::draw(key, j, adc::ST_CONV, (uint32_t)k, tick);
                                 convd = adc::bernoulli(w2.x, t_conv);
-                                if (convd) rv = adc::revenue_cents(w2.y, mu, sd);
+                                if (convd) rv = adc::revenue_cents_bm(w2.y, w2.z, mu, sd, g_log_table);
                             }
                         }
                         const unsigned long long conv_mask = __ballot(convd);
@@ -766,7 +766,7 @@ __device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint3
             const adc::U4 w2 = adc::draw(key, (uint32_t)j, adc::ST_CONV, kw, tick);
             if (adc::bernoulli(w2.x, t_conv)) {
                 conv_out += 1u;
-                rev_out += (unsigned long long)adc::revenue_cents(w2.y, mu, sd);
+                rev_out += (unsigned long long)adc::revenue_cents_bm(w2.y, w2.z, mu, sd, g_log_table);
             }
         }
     }

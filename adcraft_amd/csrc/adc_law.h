@@ -30,7 +30,7 @@ namespace adc {
 
 // IMPLICIT: call (j/4, ST_AUCTION) = one word per auction j (x,y,z,w for j%4 = 0..3); the word decides the
 //           click AND supplies the competitor-bid uniform (interval splitting, see AuctionLaw);
-//           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
+//           call (j, ST_CONV)      = {conversion, revenue u1, revenue u2} words (x,y,z), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
 enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
@@ -219,6 +219,46 @@ ADC_HD float neg_log_u24(uint32_t w24, const LogTableEntry *tab)
     r = fma32(ef, -2.12194440e-4f, r);
     r = fma32(ef, 0.693359375f, r);
     return -r;
+}
+
+// Standard normal from two words by Box-Muller: z = sqrt(-2 ln u1) * cos(2 pi u2).
+//   u1 = (odd 24-bit)/2^24 in (0,1) through the table log above; the angle is the top 24 bits of the second word:
+//   2 bits pick the quadrant, 22 bits (+1/2, so never on an axis) the position x in it; cos/sin of (pi/2) x are
+//   evaluated on (0, pi/4] after folding x -> 1 - x (Cephes single-precision minimax polynomials), then the quadrant
+//   decides which one and which sign.  No divisions, no data-dependent branches.
+ADC_HD float cos_2pi_from_word(uint32_t w)
+{
+    const uint32_t t = w >> 8;                                           // 24-bit phase
+    const uint32_t q = t >> 22;                                          // quadrant
+    const float x = ((float)(t & 0x003FFFFFu) + 0.5f) * 2.384185791015625e-07f;      // (0,1) within the quadrant
+    const bool fold = x > 0.5f;
+    const float a = (fold ? 1.0f - x : x) * 1.57079632679489661923f;     // (0, pi/4]
+    const float z = a * a;
+    float sp = fma32(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = fma32(sp, z, -1.6666654611e-1f);
+    const float sn = fma32(sp * z, a, a);                                // sin(a)
+    float cp = fma32(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = fma32(cp, z, 4.166664568298827e-2f);
+    const float cs = fma32(cp, z * z, fma32(-0.5f, z, 1.0f));            // cos(a)
+    // angle theta = (pi/2) x in the quadrant: (cos theta, sin theta) = fold ? (sn, cs) : (cs, sn)
+    const float c_th = fold ? sn : cs, s_th = fold ? cs : sn;
+    // cos(2 pi u) = cos(q pi/2 + theta):  q=0: cos  q=1: -sin  q=2: -cos  q=3: sin
+    const float v = (q & 1u) ? s_th : c_th;
+    return (q == 1u || q == 2u) ? -v : v;
+}
+
+ADC_HD float normal_box_muller(uint32_t w1, uint32_t w2, const LogTableEntry *tab)
+{
+    const float e = neg_log_u24((w1 >> 8) | 1u, tab);
+    return __builtin_sqrtf(e + e) * cos_2pi_from_word(w2);
+}
+
+// revenue of a conversion in cents, round2(max(N(mu, sd), 0.01)) (adcraft/synthetic_kw_helpers.py:66-70), IMPLICIT path
+ADC_HD int32_t revenue_cents_bm(uint32_t w1, uint32_t w2, float mu, float sd, const LogTableEntry *tab)
+{
+    float x = fma32(sd, normal_box_muller(w1, w2, tab), mu);
+    x = x > 0.01f ? x : 0.01f;
+    return money_to_cents(x);
 }
 
 // One word per auction.  click <=> word < T with T = round(ctr * 2^32) (as every Bernoulli here).  Inside

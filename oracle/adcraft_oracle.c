@@ -51,7 +51,7 @@ enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_ST
 enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
 /* IMPLICIT stream layout: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the
  * click (word < T) and, rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome);
- * call (j, ST_CONV) holds {conversion, revenue} words (x,y) of auction j and is only consumed for a paid click. */
+ * call (j, ST_CONV) holds {conversion, revenue u1, revenue u2} words (x,y,z) of auction j, only consumed for a paid click. */
 #define ORC_TIMESTEPS 24
 #define ORC_VMAX (1 << 20)
 
@@ -201,6 +201,40 @@ ORC_API float orc_neg_log_u24(uint32_t w24)
     r = fmaf(ef, -2.12194440e-4f, r);
     r = fmaf(ef, 0.693359375f, r);
     return -r;
+}
+
+/* Box-Muller normal from two words: sqrt(-2 ln u1) cos(2 pi u2); u1 through the table log, the cosine by quadrant
+ * folding to (0, pi/4] and Cephes single-precision sin/cos polynomials (no division, no libm) */
+ORC_API float orc_cos_2pi_from_word(uint32_t w)
+{
+    const uint32_t t = w >> 8, q = t >> 22;
+    const float x = ((float)(t & 0x003FFFFFu) + 0.5f) * 2.384185791015625e-07f;
+    const int fold = x > 0.5f;
+    const float a = (fold ? 1.0f - x : x) * 1.57079632679489661923f;
+    const float z = a * a;
+    float sp = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = fmaf(sp, z, -1.6666654611e-1f);
+    const float sn = fmaf(sp * z, a, a);
+    float cp = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = fmaf(cp, z, 4.166664568298827e-2f);
+    const float cs = fmaf(cp, z * z, fmaf(-0.5f, z, 1.0f));
+    const float c_th = fold ? sn : cs, s_th = fold ? cs : sn;
+    const float v = (q & 1u) ? s_th : c_th;
+    return (q == 1u || q == 2u) ? -v : v;
+}
+ORC_API float orc_normal_box_muller(uint32_t w1, uint32_t w2)
+{
+    const float e = orc_neg_log_u24((w1 >> 8) | 1u);
+    return sqrtf(e + e) * orc_cos_2pi_from_word(w2);
+}
+/* IMPLICIT revenue in cents: round2(max(N(mu, sd), 0.01))  (synthetic_kw_helpers.py:66-70) */
+ORC_API int32_t orc_revenue_cents_bm(uint32_t w1, uint32_t w2, float mu, float sd)
+{
+    float x = fmaf(sd, orc_normal_box_muller(w1, w2), mu);
+    x = fmaxf(x, 0.01f);
+    float c = rintf(x * 100.0f);
+    if (!(c < 1.0e9f)) c = 1.0e9f;
+    return (int32_t)c;
 }
 
 static uint32_t rescale_multiplier(uint64_t range)      /* floor(2^56 / range) in float32, saturated */
@@ -480,7 +514,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                         int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w2[0] < t_conv);
                         if (conv) {
                             int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
-                                                   : orc_revenue_cents_from_word(w2[1], rev_mu, rev_sd);
+                                                   : orc_revenue_cents_bm(w2[1], w2[2], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
                         }

@@ -65,6 +65,12 @@ def lib():
         L.orc_normal_from_word.argtypes = [C.c_uint32]
         L.orc_laplace_cents_from_word.restype = C.c_int32
         L.orc_laplace_cents_from_word.argtypes = [C.c_uint32, C.c_float, C.c_float]
+        L.orc_cos_2pi_from_word.restype = C.c_float
+        L.orc_cos_2pi_from_word.argtypes = [C.c_uint32]
+        L.orc_normal_box_muller.restype = C.c_float
+        L.orc_normal_box_muller.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_revenue_cents_bm.restype = C.c_int32
+        L.orc_revenue_cents_bm.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float]
         L.orc_neg_log_u24.restype = C.c_float
         L.orc_neg_log_u24.argtypes = [C.c_uint32]
         L.orc_auction_outcome.restype = C.c_int32

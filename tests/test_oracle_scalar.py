@@ -189,3 +189,20 @@ def test_auction_word_law_click_and_bid_are_independent_and_right():
     # degenerate rates
     assert L.orc_auction_outcome(123456789, 0.0, float(loc), float(scale), C.byref(click)) >= 0 and click.value == 0
     assert L.orc_auction_outcome(4294967295, 1.0, float(loc), float(scale), C.byref(click)) >= 0 and click.value == 1
+
+
+def test_box_muller_normal_and_cosine():
+    """IMPLICIT revenue normal: cos(2 pi u) against numpy over the whole phase range, and the N(0,1) law"""
+    ws = np.concatenate([np.arange(0, 2**32, 2**19, dtype=np.uint64) + np.uint64(12345), _words(20000, 31)])
+    got = np.array([L.orc_cos_2pi_from_word(int(w)) for w in ws], dtype=np.float64)
+    t = (ws >> np.uint64(8)).astype(np.float64)
+    phase = ((t // 2**22) + ((t % 2**22) + 0.5) / 2**22) / 4.0
+    assert np.abs(got - np.cos(2 * np.pi * phase)).max() < 3e-7
+    n = 300_000
+    w1, w2 = _words(n, 32), _words(n, 33)
+    z = np.array([L.orc_normal_box_muller(int(a), int(b)) for a, b in zip(w1, w2)], dtype=np.float64)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert stats.kstest(z, "norm").pvalue > 1e-4
+    mine = np.array([L.orc_revenue_cents_bm(int(a), int(b), 1.0, 0.15) for a, b in zip(w1[:200000], w2[:200000])])
+    ref = np.rint(rn.rev_normal(1.0, 0.15, np.random.default_rng(34))(200000) * 100).astype(int)
+    assert stats.ks_2samp(mine, ref).pvalue > 1e-4 and mine.min() >= 1
