@@ -34,6 +34,10 @@ class StepOut(C.Structure):
                                           "reward", "cumulative_profit", "days_passed", "terminated", "truncated")]
 
 
+class Quantiles(C.Structure):
+    _fields_ = [("buckets", C.c_int32 * 7), ("mins", C.c_void_p * 7), ("medians", C.c_void_p * 7), ("maxs", C.c_void_p * 7)]
+
+
 class Tape(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("volumes", "bid_cents", "x_impressions", "x_cost", "click", "conv", "rev_cents")]
                 + [(n, C.c_int64) for n in ("len_bid", "len_ximp", "len_xcost", "len_click", "len_conv", "len_rev")]
@@ -72,6 +76,7 @@ def lib():
         "adc_engine_get_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_set_env_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_reset": ([vp, vp, vp], C.c_int),
+        "adc_engine_generate_keywords": ([vp, C.POINTER(Quantiles), f32, C.c_uint32, vp], C.c_int),
         "adc_engine_set_limits": ([vp, i32, f64], C.c_int),
         "adc_engine_set_drift": ([vp, i32, f32, f32, f32], C.c_int),
         "adc_engine_get_rng_state": ([vp, vp, vp], C.c_int),

@@ -1193,6 +1193,20 @@ __global__ __launch_bounds__(kWave) void k_ideal_profit(View v, int n_samples, i
     if (lane == 0 && ideal_out) ideal_out[blockIdx.x] = best;           // :59
 }
 
+struct KeygenTables { adc::QuantileTable t[7]; };
+
+__global__ void k_generate_keywords(View v, KeygenTables tabs, float no_vol_prob, uint32_t serial, const uint8_t *mask)
+{
+    const int env = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= v.K || (mask && !mask[env])) return;
+    float out[8];
+    adc::generate_implicit_keyword(v.key[env], (uint32_t)k, serial, tabs.t, no_vol_prob, out);
+#pragma unroll
+    for (int p = 0; p < ADC_P_COUNT; ++p) param_at(v, p, env, k) = out[p];
+    if (k == 0) v.drift_pending[env] = 0;
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;
@@ -1539,6 +1553,41 @@ ADC_EXPORT int adc_engine_set_env_params(adc_engine *e, int env, const float *ho
     for (int p = 0; p < ADC_P_COUNT; ++p)
         HIP_TRY(hipMemcpyAsync(e->v.params + p * NK + env * K, host_8k + p * K, K * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return ADC_OK;
+}
+
+ADC_EXPORT int adc_engine_generate_keywords(adc_engine *e, const adc_quantiles *q, float no_vol_prob, uint32_t serial,
+                                            const uint8_t *env_mask)
+{
+    ENGINE_GUARD(e);
+    if (e->v.model != ADC_MODEL_IMPLICIT) return fail(ADC_EINVAL, "device keyword generation is provided for IMPLICIT keywords");
+    if (!q) return fail(ADC_EINVAL, "quantile tables are NULL");
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    KeygenTables tabs;
+    for (int i = 0; i < 7; ++i) {
+        const int B = q->buckets[i];
+        if (B <= 0 || !q->mins[i] || !q->medians[i] || !q->maxs[i]) { cleanup(); return fail(ADC_EINVAL, "every quantity needs at least one bucket"); }
+        float *d = nullptr;
+        if (hipMalloc((void **)&d, (size_t)B * 12) != hipSuccess) { cleanup(); return fail(ADC_ENOMEM, "hipMalloc (quantiles) failed"); }
+        tmp.push_back(d);
+        if (hipMemcpyAsync(d, q->mins[i], (size_t)B * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(d + B, q->medians[i], (size_t)B * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(d + 2 * B, q->maxs[i], (size_t)B * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess) { cleanup(); return fail(ADC_EHIP, "quantile upload failed"); }
+        tabs.t[i] = adc::QuantileTable{d, d + B, d + 2 * B, B};
+    }
+    uint8_t *d_mask = nullptr;
+    if (env_mask) {
+        if (hipMalloc((void **)&d_mask, (size_t)e->v.N) != hipSuccess) { cleanup(); return fail(ADC_ENOMEM, "hipMalloc (mask) failed"); }
+        tmp.push_back(d_mask);
+        if (hipMemcpyAsync(d_mask, env_mask, (size_t)e->v.N, hipMemcpyHostToDevice, e->stream) != hipSuccess) { cleanup(); return fail(ADC_EHIP, "mask upload failed"); }
+    }
+    hipLaunchKernelGGL(k_generate_keywords, dim3((unsigned)((e->v.K + 255) / 256), (unsigned)e->v.N), dim3(256), 0, e->stream, e->v, tabs,
+                       no_vol_prob, serial, d_mask);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    cleanup();
+    HIP_TRY(err);
     return ADC_OK;
 }
 

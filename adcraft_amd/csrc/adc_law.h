@@ -33,7 +33,7 @@ namespace adc {
 //           call (j, ST_CONV)      = {conversion, revenue u1, revenue u2} words (x,y,z), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
-enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
+enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8 };
 constexpr int kTimesteps = 24;          // adcraft/bidding_simulation.py:213
 constexpr int kVolumeMax = 1 << 20;
 constexpr float kMoneyMaxCents = 1.0e9f;
@@ -370,6 +370,45 @@ ADC_HD float synthetic_bid(uint32_t w, float lo, float hi)
 {
     const float b = fma32(hi - lo, unit_closed24(w), lo);
     return __builtin_rintf(b * 100.0f) / 100.0f;
+}
+
+// ---- keyword-set generation on the device (law of sample_implicit_keywords_from_quantile_dfs,
+// adcraft/gymnasium_kw_utils.py:295-339 + pull_quantiles_data/quantiles_to_keywords.py:13-28) ------------------
+// one quantile table per quantity: B buckets of (min, median, max); value = interp(q, [0, .5, 1], bucket)
+struct QuantileTable { const float *mins, *meds, *maxs; int buckets; };
+
+ADC_HD float quantile_sample(const QuantileTable &t, uint32_t w_bucket, uint32_t w_q)
+{
+    const uint32_t b = mulhi32(w_bucket, (uint32_t)t.buckets);          // rng.integers(0, B)
+    const float q = unit_closed24(w_q);                                  // rng.random()
+    const float lo = t.mins[b], md = t.meds[b], hi = t.maxs[b];
+    return q < 0.5f ? fma32((md - lo) / 0.5f, q, lo) : fma32((hi - md) / 0.5f, q - 0.5f, md);     // np.interp
+}
+
+// out[8] in adc_param order.  serial distinguishes successive generations for the same env key.
+ADC_HD void generate_implicit_keyword(uint64_t key, uint32_t kw, uint32_t serial, const QuantileTable tab[7], float no_vol_prob,
+                                      float out[8])
+{
+    const uint32_t c3 = 0xFFFF0000u | (serial & 0xFFFFu);
+    const U4 a = philox4x32_10(0u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 b = philox4x32_10(1u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 c = philox4x32_10(2u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 d = philox4x32_10(3u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const float v = quantile_sample(tab[0], a.x, a.y);
+    const float r = unit_closed24(a.w);
+    const bool has = unit_closed24(a.z) > no_vol_prob && v == v;          // :298-300 (NaN volume -> no volume)
+    out[0] = has ? __builtin_truncf(v) : 0.0f;                           // (int(v), int(1 + r * 0.5 * v))
+    out[1] = has ? __builtin_truncf(fma32(r * 0.5f, v, 1.0f)) : r * 0.5f;
+    const float cpc = quantile_sample(tab[1], b.x, b.y);
+    const float cpc_sd = quantile_sample(tab[2], b.z, b.w) * cpc;        // std_* are multipliers of the mean (:333-339)
+    out[2] = cpc;
+    out[3] = cpc_sd > 0.01f ? cpc_sd : 0.01f;
+    out[4] = quantile_sample(tab[3], c.x, c.y);
+    out[5] = quantile_sample(tab[4], c.z, c.w);
+    const float rp = quantile_sample(tab[5], d.x, d.y);
+    const float rp_sd = quantile_sample(tab[6], d.z, d.w) * rp;
+    out[6] = rp;
+    out[7] = rp_sd > 0.01f ? rp_sd : 0.01f;
 }
 
 // the 24-way split of a day's volume, adcraft/bidding_simulation.py:151-167

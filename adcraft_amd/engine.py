@@ -100,6 +100,24 @@ class StepEngine:
             raise ValueError("seeds must have shape (num_envs,)")
         check(self._lib.adc_engine_reset(self._h, ptr(m), ptr(s)))
 
+    QUANTITIES = ("vol", "ave_cpc", "std_cpc", "bctr", "sctr", "rpsc", "std_rpsc")
+
+    def generate_keywords(self, table, no_vol_prob=0.0, env_mask=None, serial=0):
+        """draw every (masked) env's keyword set on the device from a quantile table (dict of columns
+        count_/min_/median_/max_<quantity>, as the reference's DataFrame); see adc_engine_generate_keywords"""
+        q = _ffi.Quantiles()
+        keep = []
+        for i, name in enumerate(self.QUANTITIES):
+            col = lambda c: np.asarray(table[f"{c}_{name}"].to_numpy() if hasattr(table[f"{c}_{name}"], "to_numpy")  # noqa: E731
+                                       else table[f"{c}_{name}"], dtype=np.float64)
+            sel = col("count") > 0 if f"count_{name}" in table and name != "vol" else np.ones(len(col("min")), bool)
+            arrs = [np.ascontiguousarray(col(c)[sel], dtype=np.float32) for c in ("min", "median", "max")]
+            keep.append(arrs)
+            q.buckets[i] = arrs[0].size
+            q.mins[i], q.medians[i], q.maxs[i] = (a.ctypes.data for a in arrs)
+        m = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8)
+        check(self._lib.adc_engine_generate_keywords(self._h, C.byref(q), float(no_vol_prob), int(serial), ptr(m)))
+
     def set_limits(self, max_days, loss_threshold):
         check(self._lib.adc_engine_set_limits(self._h, int(max_days), float(loss_threshold)))
 

@@ -30,8 +30,9 @@ class BiddingSimulationVectorEnv:
                  device_id: int = 0, env_id_base: int = 0, autoreset: bool = True, flat: bool = False,
                  param_sampler: str = "reference", **kwargs):
         """param_sampler: "reference" draws every env's keywords with the reference's exact seeded recipe
-        (env i uses seed + i; host loop, fine up to a few thousand envs); "vectorised" draws the same law
-        for all envs at once (different stream; use it for 10^4+ envs)."""
+        (env i uses seed + i; host loop, fine up to a few thousand envs); "device" draws the same law on the GPU
+        from each env's own Philox key (no host loop, no upload; use it for 10^4+ envs); "vectorised" draws the
+        same law for all envs at once with numpy."""
         self.num_envs, self.num_keywords = int(num_envs), int(num_keywords)
         self.keyword_config = keyword_config
         self.budget = np.full(self.num_envs, float(budget), dtype=np.float32)
@@ -96,10 +97,20 @@ class BiddingSimulationVectorEnv:
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
         eng = self._ensure_engine(seed)
         if seed is not None or not self._have_keywords:
-            planes, base = self._sample_planes(seed)
-            eng.set_all_params(planes)
-            seeds = (np.arange(self.num_envs, dtype=np.uint64) + np.uint64(base + self._env_id_base))
-            eng.reset(seeds=seeds)
+            if self.param_sampler == "device":
+                if not self._implicit:
+                    raise NotImplementedError("device sampling is provided for keyword_config (implicit) envs")
+                base = int(np.random.SeedSequence().entropy % (2**62)) if seed is None else int(seed)
+                seeds = (np.arange(self.num_envs, dtype=np.uint64) + np.uint64(base + self._env_id_base))
+                eng.reset(seeds=seeds)
+                kc = self.keyword_config
+                load = kc.get("load_quant_func")
+                eng.generate_keywords(load(kc), kc.get("no_vol_prob", 0.0))
+            else:
+                planes, base = self._sample_planes(seed)
+                eng.set_all_params(planes)
+                seeds = (np.arange(self.num_envs, dtype=np.uint64) + np.uint64(base + self._env_id_base))
+                eng.reset(seeds=seeds)
             self._have_keywords = True
         else:
             eng.reset()

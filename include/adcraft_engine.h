@@ -132,6 +132,14 @@ typedef struct adc_tape {
     int64_t *end_bid, *end_ximp, *end_xcost, *end_click, *end_conv, *end_rev;         /* [N] nullable */
 } adc_tape;
 
+/* quantile tables for device-side keyword generation: the rows of the reference's quantile DataFrame, per quantity
+ * (order: vol, ave_cpc, std_cpc, bctr, sctr, rpsc, std_rpsc), already filtered to count_<param> > 0
+ * (adcraft/gymnasium_kw_utils.py:296-332) */
+typedef struct adc_quantiles {
+    int32_t buckets[7];
+    const float *mins[7], *medians[7], *maxs[7];     /* [buckets[i]] each */
+} adc_quantiles;
+
 typedef struct adc_engine adc_engine;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -147,6 +155,16 @@ int adc_engine_set_params(adc_engine *e, int param_id, const float *host_nk);
 int adc_engine_get_params(adc_engine *e, int param_id, float *host_nk);   /* applies pending drift first */
 /* all 8 planes of ONE env, host float [8][K] */
 int adc_engine_set_env_params(adc_engine *e, int env, const float *host_8k);
+
+/* draw the keyword set of every env with env_mask[e]!=0 (NULL = all) on the device: the law of
+ * sample_implicit_keywords_from_quantile_dfs (gymnasium_kw_utils.py:295-339: bucket pick + piecewise-linear
+ * interpolation, no_vol_prob, std un-normalisation), from the env's own Philox key (call after a reset with seeds);
+ * `serial` distinguishes successive generations under the same key (0 right after a seeded reset, so that the same
+ * seed reproduces the same keyword set).
+ * Same law as the host recipe, NOT the same numbers as the reference's PCG64 draws (those are reproduced by
+ * generating host-side and uploading with adc_engine_set_params). */
+int adc_engine_generate_keywords(adc_engine *e, const adc_quantiles *q, float no_vol_prob, uint32_t serial,
+                                 const uint8_t *env_mask);
 
 /* reset(): day=0, cumulative_profit=0 for envs with env_mask[e]!=0 (NULL = all);
  * seeds (nullable, [N]) re-key the env's random stream (reset(seed=...)); gymnasium_kw_env.py:271-346 */

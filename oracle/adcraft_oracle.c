@@ -48,7 +48,7 @@
 enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1 };
 enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT };
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
-enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7 };
+enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8 };
 /* IMPLICIT stream layout: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the
  * click (word < T) and, rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome);
  * call (j, ST_CONV) holds {conversion, revenue u1, revenue u2} words (x,y,z) of auction j, only consumed for a paid click. */
@@ -665,6 +665,48 @@ ORC_API void orc_sample_bids(const orc_config *c, const uint64_t *key, const uin
             draw(key[e], 0, ST_ACTION, (uint32_t)k, tick[e], w);
             float b = fmaf(hi - lo, u24(w[0]), lo);
             bids[(size_t)e * c->num_keywords + k] = rintf(b * 100.0f) / 100.0f;
+        }
+}
+
+/* ---- keyword-set generation, Philox form of gymnasium_kw_utils.py:295-339 + quantiles_to_keywords.py:13-28 ---- */
+static float quantile_sample(const float *mins, const float *meds, const float *maxs, int32_t buckets, uint32_t wb, uint32_t wq)
+{
+    const uint32_t b = (uint32_t)(((uint64_t)wb * (uint32_t)buckets) >> 32);     /* rng.integers(0, B) */
+    const float q = u24(wq);                                                       /* rng.random() */
+    const float lo = mins[b], md = meds[b], hi = maxs[b];
+    return q < 0.5f ? fmaf((md - lo) / 0.5f, q, lo) : fmaf((hi - md) / 0.5f, q - 0.5f, md);   /* np.interp(q, [0,.5,1], ...) */
+}
+/* tables: for quantity i (vol, ave_cpc, std_cpc, bctr, sctr, rpsc, std_rpsc) mins[i]/meds[i]/maxs[i] of length buckets[i];
+ * params: [8][N][K] planes, written for every env */
+ORC_API void orc_generate_implicit_keywords(int32_t N, int32_t K, const uint64_t *key, uint32_t serial, const int32_t *buckets,
+                                            const float *const *mins, const float *const *meds, const float *const *maxs,
+                                            float no_vol_prob, float *params)
+{
+    const uint32_t c3 = 0xFFFF0000u | (serial & 0xFFFFu);
+    for (int e = 0; e < N; ++e)
+        for (int k = 0; k < K; ++k) {
+            uint32_t w[4][4];
+            for (uint32_t i = 0; i < 4; ++i) {
+                uint32_t c[4] = { i, ST_KEYGEN, (uint32_t)k, c3 }, kk[2] = { (uint32_t)key[e], (uint32_t)(key[e] >> 32) };
+                orc_philox4x32_10(c, kk, w[i]);
+            }
+            float out[8];
+            const float v = quantile_sample(mins[0], meds[0], maxs[0], buckets[0], w[0][0], w[0][1]);
+            const float r = u24(w[0][3]);
+            const int has = u24(w[0][2]) > no_vol_prob && v == v;          /* :298-300 */
+            out[0] = has ? truncf(v) : 0.0f;
+            out[1] = has ? truncf(fmaf(r * 0.5f, v, 1.0f)) : r * 0.5f;
+            const float cpc = quantile_sample(mins[1], meds[1], maxs[1], buckets[1], w[1][0], w[1][1]);
+            const float cpc_sd = quantile_sample(mins[2], meds[2], maxs[2], buckets[2], w[1][2], w[1][3]) * cpc;
+            out[2] = cpc;
+            out[3] = cpc_sd > 0.01f ? cpc_sd : 0.01f;                       /* :335-339 */
+            out[4] = quantile_sample(mins[3], meds[3], maxs[3], buckets[3], w[2][0], w[2][1]);
+            out[5] = quantile_sample(mins[4], meds[4], maxs[4], buckets[4], w[2][2], w[2][3]);
+            const float rp = quantile_sample(mins[5], meds[5], maxs[5], buckets[5], w[3][0], w[3][1]);
+            const float rp_sd = quantile_sample(mins[6], meds[6], maxs[6], buckets[6], w[3][2], w[3][3]) * rp;
+            out[6] = rp;
+            out[7] = rp_sd > 0.01f ? rp_sd : 0.01f;
+            for (int p = 0; p < 8; ++p) params[((size_t)p * N + e) * K + k] = out[p];
         }
 }
 

@@ -198,3 +198,58 @@ def test_vectorised_sampler_for_large_env_counts(pkg):
     frac_zero = (obs["impressions"] == 0).mean()
     assert 0.45 < frac_zero < 0.75          # half the keywords have no volume (no_vol_prob = 0.5)
     vec.close()
+
+
+def test_device_keyword_generation_matches_oracle_and_reference_law(pkg):
+    import ctypes as C
+    from scipy import stats
+    from adcraft_amd import gymnasium_kw_utils as utils
+    from adcraft_amd.engine import StepEngine
+    from oracle import capi as orc
+    N, K = 64, 512
+    table = utils.generate_simple_experiment_quantiles(16, 0.1)
+    # a second bucket so that the bucket pick matters
+    for name, lo, md, hi in (("vol", 100, 128, 200), ("ave_cpc", 0.2, 0.4, 0.6), ("std_cpc", 0.05, 0.1, 0.2),
+                             ("bctr", 0.2, 0.3, 0.4), ("sctr", 0.5, 0.6, 0.7), ("rpsc", 1.0, 2.0, 3.0), ("std_rpsc", 0.1, 0.2, 0.3)):
+        table[f"count_{name}"].append(3)
+        table[f"min_{name}"].append(lo)
+        table[f"median_{name}"].append(md)
+        table[f"max_{name}"].append(hi)
+    e = StepEngine(N, K, seed=3)
+    e.reset(seeds=np.arange(N, dtype=np.uint64) + np.uint64(1000))
+    e.generate_keywords(table, no_vol_prob=0.3)
+    got = e.get_all_params()
+    keys, _ = e.get_rng_state()
+    # (1) bit-exact against the oracle's restatement of the same Philox recipe
+    names = StepEngine.QUANTITIES
+    arrs = [[np.ascontiguousarray(table[f"{c}_{n}"], dtype=np.float32) for n in names] for c in ("min", "median", "max")]
+    ptrs = [(C.c_void_p * 7)(*[a.ctypes.data for a in arrs[i]]) for i in range(3)]
+    buckets = (C.c_int32 * 7)(*[2] * 7)
+    ref = np.zeros((8, N, K), dtype=np.float32)
+    L = orc.lib()
+    L.orc_generate_implicit_keywords.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_generate_implicit_keywords(N, K, keys.ctypes.data, 0, buckets, ptrs[0], ptrs[1], ptrs[2], 0.3, ref.ctypes.data)
+    assert np.array_equal(got, ref)
+    # (2) same law as the reference's host recipe (PCG64): two-sample KS per parameter
+    host = np.concatenate([utils.implicit_params_to_planes(
+        utils.sample_implicit_keyword_params(K, np.random.default_rng(s), {"load_quant_func": lambda kc: table,
+                                                                           "quantiles_folder": "x", "no_vol_prob": 0.3}))
+        for s in range(N)], axis=1)
+    for p in range(8):
+        assert stats.ks_2samp(got[p].ravel(), host[p].ravel()).pvalue > 1e-4, p
+    assert abs((got[0] == 0).mean() - 0.3) < 0.01
+    e.close()
+
+
+def test_vector_env_device_sampler(pkg):
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    vec = BiddingSimulationVectorEnv(4096, keyword_config=_cfg(128, 0.8), num_keywords=64, param_sampler="device")
+    vec.reset(seed=9)
+    p1 = vec.engine.get_all_params()
+    assert (p1[0] == 128).all() and (p1[5] == np.float32(0.8)).all() and p1[2].min() >= 0.3 and p1[2].max() <= 1.0
+    obs, rew, term, trunc, _ = vec.step({"keyword_bids": np.full((4096, 64), 0.8, np.float32)})
+    assert obs["impressions"].mean() > 20
+    vec.reset(seed=9)
+    assert np.array_equal(vec.engine.get_all_params(), p1)          # same seed, same keyword sets
+    vec.close()

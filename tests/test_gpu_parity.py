@@ -395,3 +395,31 @@ def test_metric_accumulators_with_hinted_exact_pass(amd):
     kp, sc = e.metrics_read()
     assert np.array_equal(kp, prof) and sc[1] == 6 * N
     e.close()
+
+
+@pytest.mark.parametrize("K", [2048, 4096])
+def test_max_keyword_counts(amd, K):
+    """K > 1024 uses the serial walker with 40 B/keyword of dynamic LDS (160 KiB at the K = 4096 limit)"""
+    planes = H.implicit_params(1, K, seed=60 + K, mean_volume=12, cvr=0.5)
+    _run_vs_oracle(amd, 1, K, planes, steps=2, budget=1e9)
+    _run_vs_oracle(amd, 1, K, planes, steps=1, budget=30.0)
+
+
+def test_non_finite_inputs_do_not_break_the_step(amd):
+    N, K = 2, 32
+    planes = H.implicit_params(N, K, seed=61)
+    planes[4, 0, 0] = np.nan          # ctr
+    planes[7, 0, 1] = np.nan          # revenue std
+    planes[3, 0, 2] = 0.0             # degenerate competitor scale
+    bids = np.full((N, K), 0.8, np.float32)
+    bids[0, 3] = np.nan
+    bids[0, 4] = np.inf
+    bids[1, 0] = -3.0
+    e = amd.StepEngine(N, K, seed=2)
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes)
+    got, ref = e.step(bids, np.array([np.nan, 1e9], np.float32)), o.step(bids, np.array([np.nan, 1e9], np.float32))
+    H.assert_step_equal(got, ref)
+    assert got["buyside_clicks"][0].sum() == 0 and np.isfinite(got["reward"]).all()      # NaN budget pays nothing
+    e.close()
