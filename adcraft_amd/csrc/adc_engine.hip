@@ -720,9 +720,11 @@ __global__ __launch_bounds__(kWave) void k_step_exact(View v, const float *__res
 // Costs are >= 0, so remaining never increases and (a)/(c) are exact, not heuristics.
 constexpr int kRowsBlock = 256;
 constexpr int kRowsMaxK = 1024;
+constexpr int kRowsRing = 128;        // per-wave ring of paid clicks awaiting their conversion / revenue draw
 
 struct CellStat {
     unsigned int wins, clicks, first;     // first = cost of the first clicked win (0xFFFFFFFF if none)
+    unsigned int mask;                    // bit i = auction j0+i of the cell is a clicked win (cells of <= 32 auctions)
     unsigned long long total;             // cost of all clicked wins
 };
 
@@ -734,7 +736,7 @@ __device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint3
                                               float sd, long long budget, unsigned int &conv_out,
                                               unsigned long long &rev_out, unsigned long long &paid_cost)
 {
-    CellStat st{0u, 0u, 0xFFFFFFFFu, 0ull};
+    CellStat st{0u, 0u, 0xFFFFFFFFu, 0u, 0ull};
     conv_out = 0u;
     rev_out = 0ull;
     paid_cost = 0ull;
@@ -755,6 +757,7 @@ __device__ __forceinline__ CellStat walk_cell(uint64_t key, uint32_t tick, uint3
                 st.clicks += 1u;
                 st.total += (unsigned long long)comp;
                 if (st.first == 0xFFFFFFFFu) st.first = (unsigned int)comp;
+                if (j - j0 < 32) st.mask |= 1u << (j - j0);
                 continue;
             }
             if (MODE == 2) {
@@ -817,8 +820,10 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
     int *s_vol = reinterpret_cast<int *>(c_prefix + K);
     unsigned int *a_imp = reinterpret_cast<unsigned int *>(s_vol + K);
     unsigned int *a_clk = a_imp + K, *a_conv = a_clk + K;
-    unsigned int *c_wins = a_conv + K, *c_first = c_wins + K;
-    unsigned char *c_state = reinterpret_cast<unsigned char *>(c_first + K);   // 0 impressions only, 1 paid in full, 2 done, 3 not visited
+    unsigned int *c_wins = a_conv + K, *c_first = c_wins + K, *c_mask = c_first + K, *c_clicks = c_mask + K;
+    unsigned int *rings = c_clicks + K;                                         // [kRowsBlock / kWave][kRowsRing]
+    unsigned char *c_state = reinterpret_cast<unsigned char *>(rings + (kRowsBlock / kWave) * kRowsRing);
+    // c_state: 0 impressions only, 1 paid in full, 2 done, 3 not visited
 
     const int env = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -863,6 +868,8 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
             c_wins[k] = st.wins;
             c_first[k] = st.first;
             c_total[k] = st.total;
+            c_mask[k] = st.mask;
+            c_clicks[k] = st.clicks;
             c_state[k] = 1;
             my_total += (long long)st.total;
         }
@@ -920,8 +927,8 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
                     a_imp[k] += st.wins;
                     a_clk[k] += st.clicks;
                     a_cost[k] += pc;
-                    a_conv[k] += cv;
-                    a_rev[k] += rv;
+                    atomicAdd(&a_conv[k], cv);
+                    atomicAdd(&a_rev[k], rv);
                     c_state[k] = 2;
                     rs.carry = (long long)pc;
                 }
@@ -946,25 +953,72 @@ __global__ __launch_bounds__(kRowsBlock) void k_step_exact_rows(View v, const fl
         }
         __syncthreads();
         if (tid == 0) rs.remaining = R;
-        // ---- pass B: commit
-        for (int k = tid; k < K; k += kRowsBlock) {
-            const unsigned char stt = c_state[k];
-            if (stt == 0) a_imp[k] += c_wins[k];
-            else if (stt == 1) {
-                int32_t j0, n;
-                adc::cell_range(s_vol[k], t, j0, n);
-                unsigned int cv; unsigned long long rv, pc;
-                const CellStat st = walk_cell<1>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
-                                                 param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
-                                                 adc::make_auction_law(param_at(v, ADC_P_BCTR, env, k)),
-                                                 adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, k)),
-                                                 param_at(v, ADC_P_REV_MEAN, env, k), param_at(v, ADC_P_REV_STD, env, k), 0, cv, rv, pc);
-                a_imp[k] += st.wins;
-                a_clk[k] += st.clicks;
-                a_cost[k] += pc;
-                a_conv[k] += cv;
-                a_rev[k] += rv;
+        // ---- pass B: commit.  Cells paid in full take their statistics as they are; each of their clicked wins
+        // (a bit of the cell's mask) goes through a per-wave ring so that the conversion / revenue call runs on
+        // full wavefronts (as in k_step_implicit_fast).  Cells of more than 32 auctions are re-walked instead.
+        {
+            unsigned int *const ring = rings + wv * kRowsRing;
+            unsigned int qhead = 0, qtail = 0;
+            auto resolve = [&](unsigned int pos) {
+                const unsigned int ent = ring[pos & (kRowsRing - 1)];
+                const unsigned int kk = ent >> 20, j = ent & 0x000FFFFFu;          // K <= 1024, j < 2^20
+                const adc::U4 w2 = adc::draw(key, j, adc::ST_CONV, kk, tick);
+                if (adc::bernoulli(w2.x, adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, kk)))) {
+                    const int rv = adc::revenue_cents_bm(w2.y, w2.z, param_at(v, ADC_P_REV_MEAN, env, kk),
+                                                         param_at(v, ADC_P_REV_STD, env, kk), g_log_table);
+                    atomicAdd(&a_conv[kk], 1u);
+                    atomicAdd(&a_rev[kk], (unsigned long long)rv);
+                }
+            };
+            for (int kb = 0; kb < K; kb += kRowsBlock) {             // wave-uniform trip count
+                const int k = kb + tid;
+                unsigned int bits = 0;
+                int j0 = 0;
+                if (k < K) {
+                    const unsigned char stt = c_state[k];
+                    int32_t n;
+                    adc::cell_range(s_vol[k], t, j0, n);
+                    if (stt == 0) a_imp[k] += c_wins[k];
+                    else if (stt == 1 && n <= 32) {
+                        a_imp[k] += c_wins[k];
+                        a_clk[k] += c_clicks[k];
+                        a_cost[k] += c_total[k];
+                        bits = c_mask[k];
+                    } else if (stt == 1) {
+                        unsigned int cv; unsigned long long rv, pc;
+                        const CellStat st = walk_cell<1>(key, tick, (uint32_t)k, j0, n, (int)adc::bid_to_cents(bids[(size_t)env * K + k]),
+                                                         param_at(v, ADC_P_A, env, k), param_at(v, ADC_P_B, env, k),
+                                                         adc::make_auction_law(param_at(v, ADC_P_BCTR, env, k)),
+                                                         adc::bernoulli_threshold(param_at(v, ADC_P_SCTR, env, k)),
+                                                         param_at(v, ADC_P_REV_MEAN, env, k), param_at(v, ADC_P_REV_STD, env, k), 0, cv, rv, pc);
+                        a_imp[k] += st.wins;
+                        a_clk[k] += st.clicks;
+                        a_cost[k] += pc;
+                        atomicAdd(&a_conv[k], cv);
+                        atomicAdd(&a_rev[k], rv);
+                    }
+                }
+                while (__any(bits != 0u)) {                            // every lane pushes its lowest remaining click
+                    const bool has = bits != 0u;
+                    const unsigned long long m = __ballot(has);
+                    const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                    if (has) {
+                        const int i = __ffs((int)bits) - 1;
+                        bits &= bits - 1u;
+                        ring[(qtail + rank) & (kRowsRing - 1)] = ((unsigned int)k << 20) | (unsigned int)(j0 + i);
+                    }
+                    qtail += __popcll(m);
+                    while (qtail - qhead >= (unsigned int)kWave) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        resolve(qhead + lane);
+                        qhead += kWave;
+                    }
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if ((unsigned int)lane < qtail - qhead) resolve(qhead + lane);
         }
         __syncthreads();
         if (rs.stopped) break;
@@ -1399,7 +1453,7 @@ int launch_step(adc_engine *e, const float *d_bids, const float *d_budget, const
         HIP_TRY(hipGetLastError());
         if (prof) HIP_TRY(hipEventRecord(mark[1], e->stream));
         if (K <= kRowsMaxK) {
-            const size_t lds_rows = (size_t)K * (4 * 8 + 6 * 4 + 1) + 16;
+            const size_t lds_rows = (size_t)K * (4 * 8 + 8 * 4 + 1) + (kRowsBlock / kWave) * kRowsRing * 4 + 16;
             hipLaunchKernelGGL(k_step_exact_rows, dim3(N), dim3(kRowsBlock), lds_rows, e->stream, v, d_bids, d_budget);
         } else {
             hipLaunchKernelGGL((k_step_exact<ADC_MODEL_IMPLICIT, false>), dim3(N), dim3(kWave), lds, e->stream, v, d_bids, d_budget, none, 1);
