@@ -30,6 +30,7 @@
 // No CPU path exists in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
