@@ -423,3 +423,13 @@ def test_non_finite_inputs_do_not_break_the_step(amd):
     H.assert_step_equal(got, ref)
     assert got["buyside_clicks"][0].sum() == 0 and np.isfinite(got["reward"]).all()      # NaN budget pays nothing
     e.close()
+
+
+def test_random_soak_short(amd):
+    """a few seconds of tools/soak_parity.py: random shapes, laws, budgets, drift, autoreset - all bit-exact"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "6", "7"], text=True, cwd=root, timeout=300)
+    assert "soak ok" in out and "MISMATCH" not in out

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle soak: random shapes, keyword laws, budgets, drift, autoreset; every step compared
+bit for bit.  Usage: python tools/soak_parity.py [seconds] [seed]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from adcraft_amd.engine import StepEngine  # noqa: E402
+from oracle import capi as orc  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0 = time.time()
+cases = steps = reruns = 0
+while time.time() - t0 < budget_s:
+    N = int(rng.integers(1, 9))
+    K = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 255, 256, 257, 300, 511, 700, 1024, 1100]))
+    mv = float(rng.choice([0, 1, 5, 16, 40, 128, 600]))
+    planes = H.implicit_params(N, K, seed=int(rng.integers(1 << 30)), mean_volume=mv, cvr=float(rng.uniform(0, 1)),
+                               no_vol_prob=float(rng.choice([0.0, 0.3, 0.9])))
+    if rng.random() < 0.3:
+        planes[4] = rng.choice([0.0, 1.0, 0.5], size=planes[4].shape).astype(np.float32)       # extreme click rates
+    if rng.random() < 0.2:
+        planes[3] *= np.float32(rng.choice([0.0, 5.0]))                                           # degenerate / wide competitor
+    drift = bool(rng.random() < 0.4)
+    auto = bool(rng.random() < 0.5)
+    max_days = int(rng.integers(1, 5))
+    loss = float(rng.choice([1e9, 20.0]))
+    e = StepEngine(N, K, seed=int(rng.integers(1 << 30)), drift_enabled=drift, drift=(0.1, 0.2, 0.3), max_days=max_days,
+                   loss_threshold=loss, auto_reset=auto)
+    e.set_all_params(planes)
+    e.reset(seeds=rng.integers(0, 1 << 40, N).astype(np.uint64))
+    o = H.mirror_oracle(e, planes, drift_on=drift, drift=(0.1, 0.2, 0.3), max_days=max_days, loss_threshold=loss, auto_reset=auto)
+    for s in range(int(rng.integers(1, 6))):
+        bids = o.sample_bids(float(rng.uniform(0.01, 0.6)), float(rng.uniform(0.6, 2.0)))
+        budget = rng.choice([1e9, 500.0, 50.0, 5.0, 0.3, 0.0], size=N).astype(np.float32)
+        got, ref = e.step(bids, budget), o.step(bids, budget)
+        try:
+            H.assert_step_equal(got, ref)
+        except AssertionError:
+            print("MISMATCH", dict(N=N, K=K, mv=mv, drift=drift, auto=auto, step=s, budget=budget.tolist()))
+            raise
+        reruns += int((ref["cost_cents"].sum(axis=1) >= np.rint(budget.astype(np.float64) * 100)).sum())
+        steps += 1
+    if drift:
+        o.materialize_drift()
+        assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+    cases += 1
+print(f"soak ok: {cases} engines, {steps} steps, {reruns} budget-bound env-steps, {time.time() - t0:.0f} s")
