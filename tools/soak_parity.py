@@ -13,6 +13,7 @@ from tests import helpers as H  # noqa: E402
 
 budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+explicit = len(sys.argv) > 3 and sys.argv[3] == "explicit"      # the default-constructor (ExplicitKeyword) model
 t0 = time.time()
 cases = steps = reruns = 0
 while time.time() - t0 < budget_s:
@@ -25,11 +26,16 @@ while time.time() - t0 < budget_s:
         planes[4] = rng.choice([0.0, 1.0, 0.5], size=planes[4].shape).astype(np.float32)       # extreme click rates
     if rng.random() < 0.2:
         planes[3] *= np.float32(rng.choice([0.0, 5.0]))                                           # degenerate / wide competitor
+    if explicit:
+        K = min(K, 300)
+        planes = H.explicit_params(N, K, seed=int(rng.integers(1 << 30)))
+        if rng.random() < 0.3:
+            planes[0] *= np.float32(rng.choice([0.0, 4.0]))          # no volume / ~100 auctions
     drift = bool(rng.random() < 0.4)
     auto = bool(rng.random() < 0.5)
     max_days = int(rng.integers(1, 5))
     loss = float(rng.choice([1e9, 20.0]))
-    e = StepEngine(N, K, seed=int(rng.integers(1 << 30)), drift_enabled=drift, drift=(0.1, 0.2, 0.3), max_days=max_days,
+    e = StepEngine(N, K, model=1 if explicit else 0, seed=int(rng.integers(1 << 30)), drift_enabled=drift, drift=(0.1, 0.2, 0.3), max_days=max_days,
                    loss_threshold=loss, auto_reset=auto)
     e.set_all_params(planes)
     e.reset(seeds=rng.integers(0, 1 << 40, N).astype(np.uint64))
@@ -39,7 +45,7 @@ while time.time() - t0 < budget_s:
         budget = rng.choice([1e9, 500.0, 50.0, 5.0, 0.3, 0.0], size=N).astype(np.float32)
         got, ref = e.step(bids, budget), o.step(bids, budget)
         try:
-            H.assert_step_equal(got, ref)
+            H.assert_step_equal(got, ref, implicit=not explicit)
         except AssertionError:
             print("MISMATCH", dict(N=N, K=K, mv=mv, drift=drift, auto=auto, step=s, budget=budget.tolist()))
             raise
