@@ -6,8 +6,6 @@ device is usable, the error is raised to the caller.  ctypes releases the GIL du
 import ctypes as C
 import os
 
-import numpy as np
-
 from . import build as _build
 
 ADC_OK, ADC_EINVAL, ADC_EHIP, ADC_ENOMEM, ADC_ESTATE, ADC_ETYPE = 0, -1, -2, -3, -4, -5

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import gymnasium_kw_utils as utils
 from . import spaces as _spaces
-from ._ffi import MODEL_EXPLICIT, MODEL_IMPLICIT, P_A, P_B, P_BCTR, P_SCTR, P_VOL_MEAN
+from ._ffi import MODEL_EXPLICIT, MODEL_IMPLICIT, P_BCTR, P_SCTR, P_VOL_MEAN
 
 try:  # pragma: no cover - depends on the image
     import gymnasium as _gym

@@ -9,7 +9,6 @@ The samplers (cost_create, binomial_impressions, nonneg_int_normal_sampler, cost
 draw from an UNSEEDED thread_rng in the reference (src/lib.rs:25,43,61,75,320); here they draw from a
 process-wide Philox counter stream that `seed(n)` can pin.
 """
-import ctypes as C
 import itertools
 import os
 

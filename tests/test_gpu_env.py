@@ -3,7 +3,6 @@ The first block mirrors the reference's own env tests (adcraft/tests/test_env.py
 import numpy as np
 import pytest
 
-from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
