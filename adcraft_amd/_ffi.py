@@ -85,6 +85,7 @@ def lib():
         "adc_engine_step_device": ([vp, vp, vp], C.c_int),
         "adc_engine_fetch": ([vp, C.POINTER(StepOut)], C.c_int),
         "adc_engine_synchronize": ([vp], C.c_int),
+        "adc_engine_step_flat": ([vp, vp, vp, vp, vp, vp], C.c_int),
         "adc_engine_step_replay": ([vp, vp, vp, C.POINTER(Tape), C.POINTER(StepOut)], C.c_int),
         "adc_engine_update_keywords": ([vp], C.c_int),
         "adc_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),

@@ -38,6 +38,7 @@ class StepEngine:
         self._pinned = []
         self.out = {name: self._pinned_array((N, K) if per_kw else (N,), dt) for name, dt, per_kw in _OUT_SPEC}
         self._out = _ffi.StepOut(*(self.out[name].ctypes.data for name, _, _ in _OUT_SPEC))
+        self._flat_io = None
         self._bids_stage = self._pinned_array((N, K), np.float32)
         self._budget_stage = self._pinned_array((N,), np.float32)
 
@@ -56,7 +57,7 @@ class StepEngine:
         if self._h is not None:
             self._lib.adc_engine_destroy(self._h)
             self._h = None
-            self.out, self._bids_stage, self._budget_stage = {}, None, None      # drop views before freeing
+            self.out, self._bids_stage, self._budget_stage, self._flat_io = {}, None, None, None      # drop views before freeing
             for p in self._pinned:
                 self._lib.adc_host_free(p)
             self._pinned = []
@@ -157,6 +158,18 @@ class StepEngine:
         b, g = self._actions(bids, budget)
         check(self._lib.adc_engine_step(self._h, b.ctypes.data, g.ctypes.data, C.byref(self._out)))
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+    def step_flat(self, flat_actions):
+        """FlatArrayWrapper-layout step: actions float32 [N, K+1] = [budget, bids...] -> (flat_obs [N, 5K+2], reward,
+        terminated, truncated); the returned arrays are views of page-locked buffers, valid until the next step"""
+        N, K = self.num_envs, self.num_keywords
+        if self._flat_io is None:
+            self._flat_io = (self._pinned_array((N, K + 1), np.float32), self._pinned_array((N, 5 * K + 2), np.float32))
+        act, obs = self._flat_io
+        act[...] = flat_actions
+        check(self._lib.adc_engine_step_flat(self._h, act.ctypes.data, obs.ctypes.data, self.out["reward"].ctypes.data,
+                                             self.out["terminated"].ctypes.data, self.out["truncated"].ctypes.data))
+        return obs, self.out["reward"], self.out["terminated"], self.out["truncated"]
 
     def step_replay(self, bids, budget, tape, copy=True):
         b, g = self._actions(bids, budget)

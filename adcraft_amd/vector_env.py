@@ -28,11 +28,14 @@ class BiddingSimulationVectorEnv:
                  budget: float = 1000.0, loss_threshold: float = 10000.0, max_days: int = 60,
                  updater_params=(("vol", 0.03), ("ctr", 0.03), ("cvr", 0.03)), updater_mask=None,
                  device_id: int = 0, env_id_base: int = 0, autoreset: bool = True, flat: bool = False,
-                 param_sampler: str = "reference", **kwargs):
+                 param_sampler: str = "reference", copy: bool = False, **kwargs):
         """param_sampler: "reference" draws every env's keywords with the reference's exact seeded recipe
         (env i uses seed + i; host loop, fine up to a few thousand envs); "device" draws the same law on the GPU
         from each env's own Philox key (no host loop, no upload; use it for 10^4+ envs); "vectorised" draws the
-        same law for all envs at once with numpy."""
+        same law for all envs at once with numpy.
+        copy: False (default) returns observation arrays that are views of the engine's page-locked I/O buffers -
+        valid until the next step(), counts as int32 (the reference's int64 costs a 3x8 MB conversion per step at
+        4096 x 256); True returns fresh arrays with the reference's dtypes (int64 counts)."""
         self.num_envs, self.num_keywords = int(num_envs), int(num_keywords)
         self.keyword_config = keyword_config
         self.budget = np.full(self.num_envs, float(budget), dtype=np.float32)
@@ -49,6 +52,7 @@ class BiddingSimulationVectorEnv:
         self.flat = bool(flat)
         self.autoreset = bool(autoreset)
         self.param_sampler = param_sampler
+        self.copy = bool(copy)
         self._implicit = keyword_config is not None
         self._device_id, self._env_id_base = int(device_id), int(env_id_base)
         self._engine = None
@@ -146,13 +150,39 @@ class BiddingSimulationVectorEnv:
 
     def step(self, actions):
         assert self._have_keywords, "reset required, need to generate keywords to bid on"
+        N, K = self.num_envs, self.num_keywords
+        if self.flat:
+            # one array each way; un/flattening happens on the device (adc_engine_step_flat)
+            if isinstance(actions, dict):
+                a = np.empty((N, K + 1), dtype=np.float32)
+                a[:, 0] = np.asarray(actions.get("budget", self.budget), dtype=np.float32).reshape(N)
+                a[:, 1:] = np.asarray(actions["keyword_bids"], dtype=np.float32).reshape(N, K)
+                actions = a
+            obs, reward, term, trunc = self._engine.step_flat(np.asarray(actions, dtype=np.float32).reshape(N, K + 1))
+            term, trunc = term.astype(bool), trunc.astype(bool)
+            reward = reward.copy() if self.copy else reward
+            obs = obs.copy() if self.copy else obs
+            infos = {}
+            done = term | trunc
+            if self.autoreset and done.any():
+                infos["final_obs"] = obs[done].copy()
+                infos["_final_obs"] = done.copy()
+            return obs, reward, term, trunc, infos
         bids, budget = self._split_actions(actions)
-        out = self._engine.step(bids, budget, copy=True)
+        out = self._engine.step(bids, budget, copy=False)
         term, trunc = out["terminated"].astype(bool), out["truncated"].astype(bool)
-        obs = dict(impressions=out["impressions"].astype(np.int64), buyside_clicks=out["buyside_clicks"].astype(np.int64),
-                   cost=out["cost"], sellside_conversions=out["sellside_conversions"].astype(np.int64),
-                   revenue=out["revenue"], cumulative_profit=out["cumulative_profit"].astype(np.float32)[:, None],
-                   days_passed=out["days_passed"].astype(np.float32)[:, None])
+        if self.copy:
+            obs = dict(impressions=out["impressions"].astype(np.int64), buyside_clicks=out["buyside_clicks"].astype(np.int64),
+                       cost=out["cost"].copy(), sellside_conversions=out["sellside_conversions"].astype(np.int64),
+                       revenue=out["revenue"].copy(), cumulative_profit=out["cumulative_profit"].astype(np.float32)[:, None],
+                       days_passed=out["days_passed"].astype(np.float32)[:, None])
+            reward = out["reward"].copy()
+        else:
+            obs = dict(impressions=out["impressions"], buyside_clicks=out["buyside_clicks"], cost=out["cost"],
+                       sellside_conversions=out["sellside_conversions"], revenue=out["revenue"],
+                       cumulative_profit=out["cumulative_profit"].astype(np.float32)[:, None],
+                       days_passed=out["days_passed"].astype(np.float32)[:, None])
+            reward = out["reward"]
         infos = {}
         done = term | trunc
         if self.autoreset and done.any():
@@ -160,8 +190,7 @@ class BiddingSimulationVectorEnv:
             # reset() without a seed does in the reference, gymnasium_kw_env.py:303,327-328)
             infos["final_obs"] = {k: v[done].copy() for k, v in obs.items()}
             infos["_final_obs"] = done.copy()
-        obs_out = self._flatten(obs) if self.flat else obs
-        return obs_out, out["reward"], term, trunc, infos
+        return obs, reward, term, trunc, infos
 
     # device-resident stepping for policies that live on the GPU (no PCIe on the step path)
     def step_device(self, d_flat_actions=None):
@@ -239,7 +268,7 @@ class SB3VecEnvAdapter:
         dones = term | trunc
         out_infos = [{"TimeLimit.truncated": bool(tr and not te)} for te, tr in zip(term, trunc)]
         if dones.any():
-            final = self.vec._flatten(infos["final_obs"])
+            final = infos["final_obs"]
             for j, i in enumerate(np.nonzero(dones)[0]):
                 out_infos[i]["terminal_observation"] = final[j]
             obs = obs.copy()

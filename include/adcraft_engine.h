@@ -191,6 +191,12 @@ int adc_engine_step_device(adc_engine *e, const float *d_bids_nk, const float *d
 /* copy the last step's outputs to host buffers (synchronises) */
 int adc_engine_fetch(adc_engine *e, adc_step_out *out);
 int adc_engine_synchronize(adc_engine *e);
+/* the same step with FlatArrayWrapper-layout host I/O (adcraft/wrappers/flat_array.py:44-87), synchronous:
+ * flat_actions [N][K+1] = [budget, bids...] in; flat_obs [N][5K+2] (sorted-key order, see
+ * adc_engine_flat_obs_enable) out; reward [N], terminated [N], truncated [N] out (nullable).  The un/flattening
+ * happens on the device, so the host moves one array each way. */
+int adc_engine_step_flat(adc_engine *e, const float *flat_actions, float *flat_obs, double *reward, uint8_t *terminated,
+                         uint8_t *truncated);
 /* replay a recorded tape instead of the engine's own random stream (parity mode) */
 int adc_engine_step_replay(adc_engine *e, const float *bids_nk, const float *budget_n, const adc_tape *tape,
                            adc_step_out *out);
