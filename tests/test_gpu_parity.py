@@ -433,3 +433,22 @@ def test_random_soak_short(amd):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "6", "7"], text=True, cwd=root, timeout=300)
     assert "soak ok" in out and "MISMATCH" not in out
+
+
+def test_short_tape_is_an_error_not_a_fault(amd, golden):
+    t = golden("g3_implicit_replay.json")["traces"][1]
+    K = t["K"]
+    e = amd.StepEngine(1, K, seed=1)
+    e.reset()
+    tp = t["tape"]
+    for cut in ("bid", "click", "conv", "rev"):
+        kw = dict(bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"])
+        name = {"bid": "bid_cents", "click": "click", "conv": "conv", "rev": "rev_cents"}[cut]
+        kw[name] = kw[name][: len(kw[name]) // 2]
+        tape = amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), **kw)
+        with pytest.raises(ValueError, match="tape exhausted"):
+            e.step_replay(np.array(t["bids"], np.float32), t["budget"], tape)
+    with pytest.raises(ValueError, match="volume out of range"):
+        e.step_replay(np.array(t["bids"], np.float32), t["budget"],
+                      amd.ReplayTape(1, np.full((1, K), -4), bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"]))
+    e.close()
