@@ -344,6 +344,17 @@ ADC_HD int64_t budget_to_cents(float budget)
     return (int64_t)c;
 }
 
+// (double)cents / 100.0, correctly rounded, without the f64 division sequence: q0 = c * RN(1/100), one exact residual by
+// FMA, one correction (Markstein).  Equal to the IEEE quotient for every 0 <= cents < 2^31 - checked exhaustively on the
+// CPU by tests/test_oracle_scalar.py::test_cents_to_dollars_is_the_ieee_quotient.
+ADC_HD double cents_to_dollars_f64(int cents)
+{
+    const double a = (double)cents;
+    const double q0 = a * 0.01;
+    const double rem = __builtin_fma(-q0, 100.0, a);
+    return __builtin_fma(rem, 0.01, q0);
+}
+
 ADC_HD float clamp01(float v) { v = v > 0.0f ? v : 0.0f; return v < 1.0f ? v : 1.0f; }
 
 ADC_HD float threshold_sigmoid_f32(float bid, float thresh, float intercept, float slope)

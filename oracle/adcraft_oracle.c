@@ -290,6 +290,20 @@ ORC_API int64_t orc_bid_cents(float bid)
     if (c > 1.0e9) c = 1.0e9;
     return (int64_t)c;
 }
+/* checker for the product's division-free cents -> dollars (adcraft_amd/csrc/adc_law.h:cents_to_dollars_f64): counts
+ * the cents in [lo, hi) for which q0 = c*0.01; q = fma(fma(-q0,100,c), 0.01, q0) differs from the IEEE quotient c/100.0
+ * the reference computes (bidding_simulation.py:97-104 works on np.round(cost, 2) dollars). */
+ORC_API int64_t orc_check_div100(int64_t lo, int64_t hi)
+{
+    int64_t bad = 0;
+    for (int64_t c = lo; c < hi; ++c) {
+        const double a = (double)c, q0 = a * 0.01;
+        const double q = fma(fma(-q0, 100.0, a), 0.01, q0);
+        if (q != a / 100.0) ++bad;
+    }
+    return bad;
+}
+
 ORC_API int64_t orc_budget_cents(float budget)
 {
     double c = rint((double)budget * 100.0);
@@ -470,8 +484,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
     }
 
     const int64_t budget_cents = orc_budget_cents(budget_in);
-    int64_t remaining_c = budget_cents;                       /* IMPLICIT */
-    double remaining_d = (double)budget_cents / 100.0;        /* EXPLICIT: np.round(budget, 2) */
+    double remaining_d = (double)budget_cents / 100.0;        /* np.round(budget, 2), gymnasium_kw_env.py:199 */
     double *profit_k = (double *)calloc((size_t)K, sizeof(double));   /* EXPLICIT per-keyword profit */
     int stop = 0;
 
@@ -486,9 +499,15 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
             const float rev_mu = P(s, c, P_REV_MEAN, env, k), rev_sd = P(s, c, P_REV_STD, env, k);
 
             if (c->model == ORC_IMPLICIT) {
-                /* simulate_epoch_of_bidding, bidding_simulation.py:86-117, in cents */
+                /* simulate_epoch_of_bidding, bidding_simulation.py:86-117.  Money totals are carried in exact cents;
+                 * the budget walk itself is done in binary floating point exactly as the reference does it (cost =
+                 * cents/100 is the float np.around(x, 2) produced; `budget -= cost` per paid click; the campaign's
+                 * remaining budget loses sum_list(costs), a left-to-right sum) because an exact tie - remaining ==
+                 * cost - is decided there by the float residue, and whether the campaign then stops changes the
+                 * impressions of every later cell. */
                 const float loc = P(s, c, P_A, env, k), scale = P(s, c, P_B, env, k);
-                int64_t budget = remaining_c, cell_cost = 0;
+                double budget = remaining_d, cell_sum_d = 0.0;
+                int64_t cell_cost = 0;
                 int32_t wins = 0, paid = 0, convs = 0;
                 int broke = 0;
                 /* pass 1: the auctions (impressions are not budget-limited, :86-88) */
@@ -507,8 +526,9 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                     ++wins;
                     int clicked = use_tape ? tape->click[click_cur + wins - 1] : click_bit;
                     if (!clicked || broke) continue;
-                    if (budget >= comp) {                      /* :97-104 */
-                        budget -= comp; cell_cost += comp; ++paid;
+                    const double cost_d = (double)comp / 100.0;
+                    if (budget >= cost_d) {                    /* :97-104 */
+                        budget -= cost_d; cell_sum_d += cost_d; cell_cost += comp; ++paid;
                         uint32_t w2[4] = {0, 0, 0, 0};
                         if (!use_tape) draw(key, j, ST_CONV, (uint32_t)k, tick, w2);
                         int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w2[0] < t_conv);
@@ -525,8 +545,8 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                 o->clicks[base + k] += paid;
                 o->conversions[base + k] += convs;
                 o->cost_cents[base + k] += cell_cost;
-                remaining_c -= cell_cost;                       /* bidding_simulation.py:225 */
-                if (remaining_c <= 0) stop = 1;                 /* :230-233 */
+                remaining_d -= cell_sum_d;                      /* bidding_simulation.py:225 (rust.sum_list: left to right) */
+                if (remaining_d <= 0.0) stop = 1;               /* :230-233 */
             } else {
                 /* EXPLICIT cell: synthetic_kw_classes.py:535-538,514-518 then bidding_simulation.py:94-117 */
                 const float bid_d = (float)((double)bid_c / 100.0);

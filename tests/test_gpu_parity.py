@@ -452,3 +452,38 @@ def test_short_tape_is_an_error_not_a_fault(amd, golden):
         e.step_replay(np.array(t["bids"], np.float32), t["budget"],
                       amd.ReplayTape(1, np.full((1, K), -4), bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"]))
     e.close()
+
+
+# ------------------------------------------------------------------ the engine's own stream vs the reference's distributions (G9)
+def test_step_outcome_distributions_match_the_reference(amd, golden):
+    """G9: per-keyword means of every step output (and the reward) over thousands of days of the reference's own
+    Python loop, vs the engine's Philox stream on the same keywords and bids - including binding budgets, where
+    the order-dependent budget walk shapes the distribution.  z-test at 5 sigma on the difference of means."""
+    for sc in golden("g9_step_statistics.json")["scenarios"]:
+        K, N = sc["K"], 8192
+        planes = np.zeros((8, N, K), np.float32)
+        for k, p in enumerate(sc["keyword_params"]):
+            planes[:, :, k] = np.array([p["vol_mean"], p["vol_std"], p["loc"], p["scale"], p["bctr"], p["sctr"], p["rev_mean"],
+                                        p["rev_std"]], np.float32)[:, None]
+        e = amd.StepEngine(N, K, seed=2024, max_days=1 << 30, loss_threshold=1e12)
+        e.set_all_params(planes)
+        e.reset()
+        bids = np.tile(np.array(sc["bids"], np.float32), (N, 1))
+        acc = {k: [] for k in ("impressions", "buyside_clicks", "cost", "sellside_conversions", "revenue", "reward")}
+        for _ in range(4):
+            out = e.step(bids, sc["budget"])
+            for k in acc:
+                acc[k].append(out[k].astype(np.float64))
+        e.close()
+        n_eng, n_ref = 4 * N, sc["steps"]
+        for name in ("impressions", "buyside_clicks", "cost", "sellside_conversions", "revenue"):
+            x = np.concatenate(acc[name], axis=0)
+            se = np.sqrt(np.array(sc["var"][name]) / n_ref + x.var(axis=0, ddof=1) / n_eng)
+            z = (x.mean(axis=0) - np.array(sc["mean"][name])) / np.maximum(se, 1e-9)
+            assert np.abs(z).max() < 5.0, (sc["name"], name, z.tolist())
+        r = np.concatenate(acc["reward"])
+        z = (r.mean() - sc["reward_mean"]) / np.sqrt(sc["reward_var"] / n_ref + r.var(ddof=1) / n_eng)
+        assert abs(z) < 5.0, (sc["name"], "reward", z)
+        if sc["budget"] < 1e8:     # the budget really binds, and is never overspent
+            spend = np.concatenate(acc["cost"], axis=0).sum(axis=1)
+            assert spend.max() <= sc["budget"] + 1e-3 and (spend > sc["budget"] - 1.5).mean() > 0.2

@@ -206,3 +206,11 @@ def test_box_muller_normal_and_cosine():
     mine = np.array([L.orc_revenue_cents_bm(int(a), int(b), 1.0, 0.15) for a, b in zip(w1[:200000], w2[:200000])])
     ref = np.rint(rn.rev_normal(1.0, 0.15, np.random.default_rng(34))(200000) * 100).astype(int)
     assert stats.ks_2samp(mine, ref).pvalue > 1e-4 and mine.min() >= 1
+
+
+def test_cents_to_dollars_is_the_ieee_quotient():
+    """The product turns cents into the reference's float dollars without an f64 division
+    (adc_law.h:cents_to_dollars_f64); the budget walk's float comparisons (bidding_simulation.py:97-104, 225-233)
+    need it equal to c / 100.0 for every cost that can occur."""
+    assert L.orc_check_div100(0, 1 << 26) == 0
+    assert L.orc_check_div100((1 << 31) - (1 << 22), 1 << 31) == 0

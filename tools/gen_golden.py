@@ -270,9 +270,18 @@ def gen_g3(u, b, c):
         (17, 4, 30, 0.5, None, 3.0, (0.6, 1.4)),
         (18, 16, 300, 0.8, None, 1.0e9, (0.2, 0.9)),    # V > 24*... exercises all 24 sub-steps
         (19, 3, 128, 0.8, None, 0.05, (0.5, 1.2)),      # budget smaller than most clicks
+        # tie-rich: competitor bids concentrated on 2-3 cent values, budget a multiple of the typical cost, so
+        # "remaining == cost" happens and the reference's float residue decides whether the campaign stops
+        (20, 6, 64, 0.8, None, 5.0, (0.7, 1.0), (0.50, 0.002)),
+        (21, 6, 64, 0.8, None, 2.5, (0.7, 1.0), (0.50, 0.002)),
+        (22, 4, 128, 0.8, None, 10.0, (0.6, 0.9), (0.25, 0.001)),
+        (23, 8, 40, 0.5, None, 1.0, (0.6, 0.9), (0.10, 0.001)),
+        (24, 5, 100, 0.8, None, 7.0, (0.9, 1.2), (0.35, 0.003)),
     ]
     import adcraft.experiment_utils.experiment_quantiles as eq
-    for (seed, K, mv, cvr, nvp, budget, (blo, bhi)) in spec:
+    for row in spec:
+        (seed, K, mv, cvr, nvp, budget, (blo, bhi)) = row[:7]
+        override = row[7] if len(row) > 7 else None
         tries = 0
         while True:
             rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + 1000 * tries)))
@@ -287,6 +296,8 @@ def gen_g3(u, b, c):
             for p in params:
                 vol = (float(p[0][0]), float(p[0][1]))
                 loc, scale = f32x(p[1]), f32x(1.0 / p[2])
+                if override is not None:
+                    loc, scale = f32x(override[0]), f32x(override[1])
                 bctr, sctr, mu, sd = f32x(p[3]), f32x(p[4]), f32x(p[5]), f32x(p[6])
                 v = int(max(0.0, np.floor(rng.normal(vol[0], max(vol[1], 1e-9)) + 0.5)))
                 vols.append(v)
@@ -331,14 +342,12 @@ def gen_g3(u, b, c):
             # coinflip calls alternate click, conv per visited cell
             for i, arr in enumerate(calls):
                 tape["click" if i % 2 == 0 else "conv"].extend([int(x) for x in arr])
-            # tie scan in exact cents: replay the budget walk and measure |remaining - cost|
-            ok = tie_free(vols, bids, budget, tape, K)
-            if ok:
-                break
-            tries += 1
-            assert tries < 50
+            # exact ties (remaining == cost, or the campaign's remaining hitting exactly zero) are KEPT: the
+            # restatement reproduces the reference's float arithmetic there; has_tie is recorded for information
+            has_tie = not tie_free(vols, bids, budget, tape, K)
+            break
         traces.append(dict(
-            seed=seed, tries=tries, K=K, budget=budget, bids=bids, volumes=vols, keyword_params=kp,
+            seed=seed, tries=tries, has_tie=has_tie, K=K, budget=budget, bids=bids, volumes=vols, keyword_params=kp,
             tape=tape,
             out=dict(impressions=[int(o["impressions"]) for o in outcomes],
                      buyside_clicks=[int(o["buyside_clicks"]) for o in outcomes],
@@ -697,10 +706,7 @@ def gen_g8(env_mod, eq, c, rust):
             sl = st_["tape_slices"]
             ok = ok and tie_free(st_["volumes"], st_["bids"], budget,
                                  {k: tape[k][sl[k][0]:sl[k][1]] for k in tape}, K)
-        if not ok:
-            todo.insert(0, (seed, K, mv, cvr, budget, loss_thr, max_days, drift, tries + 1))
-            continue
-        eps.append(dict(seed=seed, tries=tries, K=K, budget=budget, loss_threshold=loss_thr, max_days=max_days,
+        eps.append(dict(seed=seed, tries=tries, has_tie=not ok, K=K, budget=budget, loss_threshold=loss_thr, max_days=max_days,
                         drift=drift, params0=params0, tape=tape, steps=steps))
     dump("g8_env_episodes.json", dict(
         source="adcraft/gymnasium_kw_env.py:160-269 (BiddingSimulation.step) executed unmodified over recorded "
