@@ -48,5 +48,19 @@ def build(force=False, verbose=False, extra=()):
     return LIB
 
 
+def build_timing_variant():
+    """lib/variants/timing.so: the same library with in-kernel phase timers (-DADC_EXP_TIMING); select it with
+    ADCRAFT_HIP_LIB=<path> (tools/exp_rows_timing.py).  Never loaded by default."""
+    out_dir = os.path.join(LIB_DIR, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "timing.so")
+    srcs = [os.path.join(SRC_DIR, s) for s in SOURCES]
+    subprocess.check_call([HIPCC] + FLAGS + ["-DADC_EXP_TIMING", "-Wno-unused-value"] + srcs + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--timing" in sys.argv:
+        print(build_timing_variant())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))
