@@ -70,6 +70,17 @@ def lib():
         "adc_device_count": ([vp], C.c_int),
         "adc_engine_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
         "adc_engine_destroy": ([vp], None),
+        "adc_engine_bid_curves_build": ([vp, C.c_int, vp, C.c_int], C.c_int),
+        "adc_engine_ideal_step": ([vp, vp, vp], C.c_int),
+        "adc_engine_bid_curves_fetch": ([vp, vp, vp], C.c_int),
+        "adc_engine_policy_oracle": ([vp, f32], C.c_int),
+        "adc_engine_agent_init": ([vp, f32, vp], C.c_int),
+        "adc_engine_agent_update": ([vp, vp, vp, vp], C.c_int),
+        "adc_engine_agent_act": ([vp, f32, vp], C.c_int),
+        "adc_engine_agent_step": ([vp, f32], C.c_int),
+        "adc_engine_agent_state": ([vp, vp, vp, vp, vp, vp], C.c_int),
+        "adc_engine_get_actions": ([vp, vp, vp], C.c_int),
+        "adc_engine_metrics_read_nk": ([vp, vp, vp, vp], C.c_int),
         "adc_engine_set_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_get_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_set_env_params": ([vp, C.c_int, vp], C.c_int),

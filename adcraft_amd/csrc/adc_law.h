@@ -33,7 +33,7 @@ namespace adc {
 //           call (j, ST_CONV)      = {conversion, revenue u1, revenue u2} words (x,y,z), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
-enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8 };
+enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8, ST_AGENT = 9 };
 constexpr int kTimesteps = 24;          // adcraft/bidding_simulation.py:213
 constexpr int kVolumeMax = 1 << 20;
 constexpr float kMoneyMaxCents = 1.0e9f;

@@ -26,6 +26,7 @@ class StepEngine:
         self._h = None
         self._lib = _ffi.lib()
         self.num_envs, self.num_keywords, self.model = int(num_envs), int(num_keywords), int(model)
+        self.max_days = int(max_days)
         cfg = _ffi.Config(C.sizeof(_ffi.Config), int(device_id), self.num_envs, self.num_keywords, self.model,
                           int(max_days), float(loss_threshold), float(drift[0]), float(drift[1]), float(drift[2]),
                           1 if drift_enabled else 0, float(impression_thresh), 1 if auto_reset else 0,
@@ -121,6 +122,7 @@ class StepEngine:
 
     def set_limits(self, max_days, loss_threshold):
         check(self._lib.adc_engine_set_limits(self._h, int(max_days), float(loss_threshold)))
+        self.max_days = int(max_days)
 
     def set_drift(self, enabled, drift=(0.03, 0.03, 0.03)):
         check(self._lib.adc_engine_set_drift(self._h, 1 if enabled else 0, float(drift[0]), float(drift[1]), float(drift[2])))
@@ -241,6 +243,84 @@ class StepEngine:
         sc = np.zeros(8, dtype=np.int64)
         check(self._lib.adc_engine_metrics_read(self._h, kp.ctypes.data, sc.ctypes.data))
         return kp, sc
+
+
+    # ---- device-resident callers of the step: per-step ideal profit and the baseline bidders --------------------
+    def bid_curves_build(self, n_samples=2048, bid_grid=None):
+        """cache get_implicit_kw_bid_cpc_impressions of every keyword on the device (experiment_metrics.py:20-37)"""
+        grid = np.ascontiguousarray(np.arange(0.01, 3.00, 0.01) if bid_grid is None else bid_grid, dtype=np.float64)
+        check(self._lib.adc_engine_bid_curves_build(self._h, int(n_samples), grid.ctypes.data, grid.size))
+        self._bid_grid = grid
+
+    def bid_curves_fetch(self):
+        """the cached curves as host arrays (impression_rate, cpc), each [N, K, n_bids]"""
+        nb = self._bid_grid.size
+        ir = np.zeros((self.num_envs, self.num_keywords, nb), np.float64)
+        cpc = np.zeros((self.num_envs, self.num_keywords, nb), np.float64)
+        check(self._lib.adc_engine_bid_curves_fetch(self._h, ir.ctypes.data, cpc.ctypes.data))
+        return ir, cpc
+
+    def ideal_step(self, fetch=True):
+        """get_max_expected_bid_profits for the current parameters against the cached curves; with metrics enabled
+        the ideal is also accumulated.  Returns (ideal [N, K] dollars, argmax index [N, K]) or None if not fetch."""
+        if not fetch:
+            check(self._lib.adc_engine_ideal_step(self._h, None, None))
+            return None
+        ideal = np.zeros((self.num_envs, self.num_keywords), dtype=np.float64)
+        best = np.zeros((self.num_envs, self.num_keywords), dtype=np.int32)
+        check(self._lib.adc_engine_ideal_step(self._h, ideal.ctypes.data, best.ctypes.data))
+        return ideal, best
+
+    def policy_oracle(self, budget=100000.0):
+        """next action := the grid bid of maximum expected profit (after ideal_step)"""
+        check(self._lib.adc_engine_policy_oracle(self._h, float(budget)))
+
+    def agent_init(self, default_rpc=3.0, seeds=None):
+        sd = None if seeds is None else np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.num_envs,)))
+        check(self._lib.adc_engine_agent_init(self._h, float(default_rpc), None if sd is None else sd.ctypes.data))
+
+    def agent_update(self, clicks=None, conversions=None, revenue=None):
+        if clicks is None and conversions is None and revenue is None:
+            check(self._lib.adc_engine_agent_update(self._h, None, None, None))
+            return
+        shape = (self.num_envs, self.num_keywords)
+        c = np.ascontiguousarray(np.asarray(clicks).reshape(shape), dtype=np.int32)
+        v = np.ascontiguousarray(np.asarray(conversions).reshape(shape), dtype=np.int32)
+        r = np.ascontiguousarray(np.asarray(revenue).reshape(shape), dtype=np.float32)
+        check(self._lib.adc_engine_agent_update(self._h, c.ctypes.data, v.ctypes.data, r.ctypes.data))
+
+    def agent_act(self, budget_override=0.0, replay_uniforms=None):
+        u = None
+        if replay_uniforms is not None:
+            u = np.ascontiguousarray(np.asarray(replay_uniforms, dtype=np.float64).reshape(self.num_envs, self.num_keywords))
+        check(self._lib.adc_engine_agent_act(self._h, float(budget_override), None if u is None else u.ctypes.data))
+
+    def agent_step(self, budget_override=0.0):
+        check(self._lib.adc_engine_agent_step(self._h, float(budget_override)))
+
+    def agent_state(self):
+        shape = (self.num_envs, self.num_keywords)
+        st = dict(ave_rpc=np.zeros(shape, np.float32), num_rpc_obs=np.zeros(shape, np.int32), ave_sctr=np.zeros(shape, np.float32),
+                  num_sctr_obs=np.zeros(shape, np.int32), max_bids=np.zeros(shape, np.float64))
+        check(self._lib.adc_engine_agent_state(self._h, *(st[k].ctypes.data for k in ("ave_rpc", "num_rpc_obs", "ave_sctr",
+                                                                                      "num_sctr_obs", "max_bids"))))
+        return st
+
+    def get_actions(self):
+        bids = np.zeros((self.num_envs, self.num_keywords), np.float32)
+        budget = np.zeros(self.num_envs, np.float32)
+        check(self._lib.adc_engine_get_actions(self._h, bids.ctypes.data, budget.ctypes.data))
+        return bids, budget
+
+    def metrics_read_nk(self, ideal=True):
+        """per (env, keyword) sums: profit in dollars, and (if ideal) the ideal sum and the ideal sum with <= 0 -> 1"""
+        shape = (self.num_envs, self.num_keywords)
+        pc = np.zeros(shape, np.int64)
+        si = np.zeros(shape, np.float64) if ideal else None
+        sp = np.zeros(shape, np.float64) if ideal else None
+        check(self._lib.adc_engine_metrics_read_nk(self._h, pc.ctypes.data, None if si is None else si.ctypes.data,
+                                                   None if sp is None else sp.ctypes.data))
+        return pc / 100.0, si, sp
 
 
 class ReplayTape:

@@ -243,6 +243,50 @@ int adc_engine_ideal_profit(adc_engine *e, int n_samples, const double *bid_grid
 int adc_bid_curves_from_samples(int device_id, const int32_t *samples_cents, int32_t n_samples, const double *bid_grid,
                                 int32_t n_bids, double *impression_rate_out, double *cpc_out);
 
+/* ---- the callers of the step, device-resident: per-step ideal profit and the paper's baseline bidders ----------
+ * (the loop of adcraft/baseline_experiment_and_figs_notebooks/run_heatmap_experiments.ipynb cell 1 and
+ * timing_and_other_one_off_experiments.ipynb cell 2: agent.update_all_caches -> agent.sample_action ->
+ * get_max_expected_bid_profits per keyword -> env.step -> profits).  All of it runs on the engine's stream against the
+ * engine's device-resident observation and action buffers: no host round trip per step. */
+
+/* impression-rate / expected-cpc curves of every keyword on `bid_grid` from n_samples sampled competitor bids
+ * (get_implicit_kw_bid_cpc_impressions, experiment_metrics.py:20-37; the notebooks build them once after reset()).
+ * Kept on the device: 16 bytes x N x K x n_bids. */
+int adc_engine_bid_curves_build(adc_engine *e, int n_samples, const double *bid_grid, int n_bids);
+/* the cached curves to host: impression rate and expected cpc, double [N*K][n_bids] each (either may be NULL) */
+int adc_engine_bid_curves_fetch(adc_engine *e, double *impression_rate_host, double *cpc_host);
+/* get_max_expected_bid_profits (experiment_metrics.py:40-61) for the CURRENT (drifted) parameters against the cached
+ * curves: max expected profit and its argmax over the grid, per keyword; host outputs may be NULL.  With metrics
+ * enabled the value is also added to the per-keyword ideal sums (raw, and with <= 0 replaced by 1 as compute_AKNCP
+ * does, :71-75). */
+int adc_engine_ideal_step(adc_engine *e, double *ideal_host_nk, int32_t *best_index_host_nk);
+/* run_oracle_agent: next action := bid_grid[argmax] of the last adc_engine_ideal_step, budget as given */
+int adc_engine_policy_oracle(adc_engine *e, float budget);
+
+/* NaiveZeroMarginStrategy (adcraft/baselines/interpolated_expectations.py:442-515), one agent per env.
+ * init: empty caches (:286-295), max_bids = 0.01 (:481), the agent's Philox stream keyed by seeds_n (NULL: derived
+ * from adc_config.seed and the env id). */
+int adc_engine_agent_init(adc_engine *e, float default_expected_revenue_per_conversion, const uint64_t *seeds_n);
+/* update_all_caches (:485-494) with one observation per keyword: host arrays [N*K] (all three), or all NULL = the
+ * engine's last observation where it lies on the device (after reset: zeros, as the reference's reset observation) */
+int adc_engine_agent_update(adc_engine *e, const int32_t *clicks_nk, const int32_t *conversions_nk, const float *revenue_nk);
+/* sample_action (:496-515) into the engine's action buffers (what adc_engine_step_device(e, NULL, NULL) consumes).
+ * budget_override > 0 replaces the agent's 100 x sum(codes) budget (the notebooks pass budget = 100000 to the env).
+ * replay_uniforms_nk (host double [N*K], nullable): the rng.random() value to use for each keyword instead of the
+ * agent's Philox stream - parity mode against recorded reference runs. */
+int adc_engine_agent_act(adc_engine *e, float budget_override, const double *replay_uniforms_nk);
+/* update from the device-resident observation + act, one launch (the closed loop's per-step call) */
+int adc_engine_agent_step(adc_engine *e, float budget_override);
+/* caches to host (any pointer may be NULL): ave_rpc, num_rpc_obs, ave_sctr, num_sctr_obs, max_bids, each [N*K] */
+int adc_engine_agent_state(adc_engine *e, float *ave_rpc_nk, int32_t *num_rpc_obs_nk, float *ave_sctr_nk,
+                           int32_t *num_sctr_obs_nk, double *max_bids_nk);
+/* the engine's device action buffers to host (what a policy above, adc_engine_sample_actions or
+ * adc_engine_set_flat_actions_device last wrote) */
+int adc_engine_get_actions(adc_engine *e, float *bids_nk, float *budget_n);
+/* per (env, keyword) metric sums to host (any pointer may be NULL): profit in cents, ideal, ideal with <= 0 -> 1;
+ * per-env AKNCP = median_k(profit / ideal_pos), NCP = sum profit / sum ideal (experiment_metrics.py:64-83) */
+int adc_engine_metrics_read_nk(adc_engine *e, int64_t *profit_cents_nk, double *ideal_sum_nk, double *ideal_pos_sum_nk);
+
 /* ---- standalone auction clearing (adcraft/synthetic_kw_helpers.py:116-180) ------------------------ */
 /* other_bids: host double [n_auctions][n_bidders]; placements/costs: host, capacity n_auctions.
  * Returns the impression count in *impressions.  num_winners + n must be <= 32. */

@@ -222,3 +222,23 @@ def test_g8_env_episodes(golden):
             sl = st["tape_slices"]
             assert (cur["bid"], cur["click"], cur["conv"], cur["rev"]) == (sl["bid"][1], sl["click"][1], sl["conv"][1], sl["rev"][1])
     assert any(st["truncated"] for ep in golden("g8_env_episodes.json")["episodes"] for st in ep["steps"])
+
+
+def test_g10_zero_margin_agent_restatement(golden):
+    """G10: the reference's NaiveZeroMarginStrategy, run unmodified in the notebooks' loop; the restatement must
+    return the same float64 bids, the same budget and hold the same caches after every step."""
+    for c in golden("g10_zero_margin_agent.json")["cases"]:
+        a = rn.ZeroMarginAgent(1, c["K"], c["default_rpc"])
+        for t, s in enumerate(c["steps"]):
+            a.update(np.array([s["obs_clicks"]]), np.array([s["obs_conversions"]]), np.array([s["obs_revenue"]]))
+            u = np.array([s["uniforms"]])
+            assert np.array_equal(np.isfinite(u[0]), a.num_rpc_obs[0] < 1)        # it draws exactly where no rpc was seen
+            bids, budget = a.act(np.where(np.isnan(u), 0.5, u))
+            assert np.array_equal(bids[0], np.array(s["bids"])), t
+            assert budget[0] == s["budget"]
+            assert np.array_equal(a.ave_rpc[0].astype(np.float64), np.array(s["ave_rpc"]))
+            assert np.array_equal(a.num_rpc_obs[0], np.array(s["num_rpc_obs"]))
+            seen = a.num_sctr_obs[0] > 0
+            assert np.array_equal(a.ave_sctr[0].astype(np.float64)[seen], np.array(s["ave_sctr"])[seen])
+            assert np.array_equal(a.num_sctr_obs[0].astype(np.float64), np.array(s["num_sctr_obs"]))
+            assert np.array_equal(a.max_bids[0], np.array(s["max_bids"]))
