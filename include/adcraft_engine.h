@@ -251,7 +251,7 @@ int adc_bid_curves_from_samples(int device_id, const int32_t *samples_cents, int
 
 /* impression-rate / expected-cpc curves of every keyword on `bid_grid` from n_samples sampled competitor bids
  * (get_implicit_kw_bid_cpc_impressions, experiment_metrics.py:20-37; the notebooks build them once after reset()).
- * Kept on the device: 16 bytes x N x K x n_bids. */
+ * Kept on the device as integer numerators, 8 bytes x N x K x n_bids; n_samples <= 2^20. */
 int adc_engine_bid_curves_build(adc_engine *e, int n_samples, const double *bid_grid, int n_bids);
 /* the cached curves to host: impression rate and expected cpc, double [N*K][n_bids] each (either may be NULL) */
 int adc_engine_bid_curves_fetch(adc_engine *e, double *impression_rate_host, double *cpc_host);

@@ -53,5 +53,5 @@ ncp = profit.sum(axis=1) / np.maximum(ideal.sum(axis=1), 1e-9)
 akncp = np.median(profit / ideal_pos, axis=1)
 print(json.dumps(dict(config=cfg, policy=policy, drift=drift, num_envs=N, num_keywords=K, steps=steps,
                       ms_per_loop_step=1e3 * dt / steps, keyword_steps_per_s=N * K * steps / dt,
-                      bid_curves_build_s=t_curves, bid_curves_bytes=int(N) * K * 299 * 16,
+                      bid_curves_build_s=t_curves, bid_curves_bytes=int(N) * K * 299 * 8,
                       median_NCP=float(np.median(ncp)), median_AKNCP=float(np.median(akncp)))))
