@@ -307,8 +307,8 @@ ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float
     const uint32_t d = click ? w : w - a.t32;
     uint32_t i24 = mulhi32(d, click ? a.m_click : a.m_noclick);
     i24 = i24 < 0x00FFFFFFu ? i24 : 0x00FFFFFFu;
-    const float e = neg_log_u24(i24 | 1u, tab);                  // u = (2*mag + 1) / 2^24 in (0,1), mag = i24 >> 1
-    const float z = (i24 & 1u) ? e : -e;
+    const float r = -neg_log_u24(i24 | 1u, tab);                 // log u <= 0, u = (2*mag + 1) / 2^24 in (0,1), mag = i24 >> 1
+    const float z = bits_to_float(float_to_bits(r) ^ (i24 << 31));                  // bit 0 set: -log u, clear: +log u
     return money_to_cents(__builtin_fabsf(fma32(scale, z, loc)));
 }
 
