@@ -399,7 +399,8 @@ def test_metric_accumulators_with_hinted_exact_pass(amd):
 
 @pytest.mark.parametrize("K", [2048, 4096])
 def test_max_keyword_counts(amd, K):
-    """K > 1024 uses the serial walker with 40 B/keyword of dynamic LDS (160 KiB at the K = 4096 limit)"""
+    """K <= 2048: the row kernel with 73 B/keyword of dynamic LDS (146 KiB); beyond: the serial walker with 40 B/keyword
+    (160 KiB at the K = 4096 limit)"""
     planes = H.implicit_params(1, K, seed=60 + K, mean_volume=12, cvr=0.5)
     _run_vs_oracle(amd, 1, K, planes, steps=2, budget=1e9)
     _run_vs_oracle(amd, 1, K, planes, steps=1, budget=30.0)
