@@ -81,6 +81,8 @@ def lib():
         "adc_engine_agent_state": ([vp, vp, vp, vp, vp, vp], C.c_int),
         "adc_engine_get_actions": ([vp, vp, vp], C.c_int),
         "adc_engine_metrics_read_nk": ([vp, vp, vp, vp], C.c_int),
+        "adc_engine_run_days": ([vp, C.c_int, i32, f32], C.c_int),
+        "adc_engine_day_graph_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_set_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_get_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_set_env_params": ([vp, C.c_int, vp], C.c_int),

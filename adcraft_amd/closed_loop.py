@@ -27,14 +27,7 @@ def run_baseline_episode(engine, policy="zero_margin", steps=None, budget=100000
     engine.metrics_reset()
     if policy == "zero_margin":
         engine.agent_init(default_rpc, agent_seeds)
-    for _ in range(steps):
-        if policy == "zero_margin":
-            engine.agent_step(budget)          # update from the device-resident observation, then act
-            engine.ideal_step(fetch=False)     # accumulates the step's ideal profit
-        else:
-            engine.ideal_step(fetch=False)
-            engine.policy_oracle(budget)
-        engine.step_device()
+    engine.run_days(policy, steps, budget)     # agent / ideal profit / step for every day, one host call
     profit, ideal, ideal_pos = engine.metrics_read_nk()
     n = float(steps)
     with np.errstate(divide="ignore", invalid="ignore"):

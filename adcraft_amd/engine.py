@@ -312,6 +312,15 @@ class StepEngine:
         check(self._lib.adc_engine_get_actions(self._h, bids.ctypes.data, budget.ctypes.data))
         return bids, budget
 
+    POLICIES = {"fixed": 0, "zero_margin": 1, "oracle": 2}
+
+    def run_days(self, policy, days, budget=100000.0, graph=None):
+        """`days` days of the device-resident loop in one call; graph=True replays pairs of days from a captured
+        hipGraph (same results, measured no faster: tools/measure_small_loop.py)"""
+        if graph is not None:
+            check(self._lib.adc_engine_day_graph_enable(self._h, 1 if graph else 0))
+        check(self._lib.adc_engine_run_days(self._h, self.POLICIES[policy], int(days), float(budget)))
+
     def metrics_read_nk(self, ideal=True):
         """per (env, keyword) sums: profit in dollars, and (if ideal) the ideal sum and the ideal sum with <= 0 -> 1"""
         shape = (self.num_envs, self.num_keywords)

@@ -283,6 +283,14 @@ int adc_engine_agent_state(adc_engine *e, float *ave_rpc_nk, int32_t *num_rpc_ob
 /* the engine's device action buffers to host (what a policy above, adc_engine_sample_actions or
  * adc_engine_set_flat_actions_device last wrote) */
 int adc_engine_get_actions(adc_engine *e, float *bids_nk, float *budget_n);
+/* `days` consecutive days of the device-resident loop in one call: per day, the policy writes the action
+ * (FIXED_ACTIONS: whatever the action buffers hold; ZERO_MARGIN: adc_engine_agent_step, plus adc_engine_ideal_step when
+ * curves are built; ORACLE: adc_engine_ideal_step + adc_engine_policy_oracle), then the env steps.  Asynchronous on
+ * the engine's stream.  adc_engine_day_graph_enable(e, 1) makes it replay pairs of days from a captured hipGraph
+ * (same results; measured no faster on MI355X - the dependent kernels of a day are latency-, not launch-bound). */
+enum adc_policy { ADC_POLICY_FIXED_ACTIONS = 0, ADC_POLICY_ZERO_MARGIN = 1, ADC_POLICY_ORACLE = 2 };
+int adc_engine_run_days(adc_engine *e, int policy, int32_t days, float budget);
+int adc_engine_day_graph_enable(adc_engine *e, int enabled);
 /* per (env, keyword) metric sums to host (any pointer may be NULL): profit in cents, ideal, ideal with <= 0 -> 1;
  * per-env AKNCP = median_k(profit / ideal_pos), NCP = sum profit / sum ideal (experiment_metrics.py:64-83) */
 int adc_engine_metrics_read_nk(adc_engine *e, int64_t *profit_cents_nk, double *ideal_sum_nk, double *ideal_pos_sum_nk);

@@ -162,3 +162,34 @@ def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
         assert np.allclose(runs[0][1], runs[1][1], rtol=1e-5, atol=1e-7), policy
     # the oracle bidder earns about the ideal (NCP near 1), the ramping agent less in 15 days
     assert 0.6 < np.median(runs[0][1]) < 1.4
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_run_days_graph_replay_equals_single_steps(amd, model):
+    """adc_engine_run_days, plain and replaying pairs of days from a captured hipGraph: same trajectory as one call per
+    day, for odd and even day counts, repeated calls (parity re-alignment) and both models"""
+    N, K = 6, 48
+    planes = H.implicit_params(N, K, seed=95, mean_volume=20, cvr=0.6) if model == 0 else H.explicit_params(N, K, seed=95)
+    outs = []
+    for graph in (True, False, None):
+        e = amd.StepEngine(N, K, model=model, seed=31, drift_enabled=True, drift=(0.05, 0.05, 0.05), max_days=1 << 20,
+                           loss_threshold=1e12)
+        e.set_all_params(planes)
+        e.reset()
+        e.sample_actions(0.3, 1.0, 35.0)              # a budget that binds on some days
+        e.metrics_enable(True)
+        for days in (1, 7, 4, 5, 2):
+            if graph is not None:
+                e.run_days("fixed", days, graph=graph)
+            else:
+                for _ in range(days):
+                    e.step_device()
+        o = e.fetch()
+        outs.append((o, e.get_all_params(), e.metrics_read_nk(ideal=False)[0], e.get_rng_state()))
+        e.close()
+    for a in outs[:2]:
+        b = outs[2]
+        for k in a[0]:
+            assert np.array_equal(a[0][k], b[0][k]), k
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
