@@ -143,11 +143,13 @@ def main():
         dom = int(np.argmax(kernel_ms))              # the dominant kernel of the step
         k_ms = kernel_ms[dom] / max(launches, 1)
         achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch") if dom == 0 else None
+                pmc_cfg = json.load(open(pmc)).get(args.config, {})
+                traffic = pmc_cfg.get("hbm_bytes_per_launch") if dom == 0 else None
+                valu = pmc_cfg.get("valu") if dom == 0 else None
             except Exception:
                 traffic = None
         line = {
@@ -169,6 +171,12 @@ def main():
                          "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(names, kernel_ms)},
                          "algorithmic_bytes_per_launch": b_alg},
         }
+        if valu and launches:
+            # why the HBM fraction is low on dense configs: the kernel is VALU-issue-bound (static PMC counts of this
+            # workload from profiles/pmc_traffic.json, divided by the live kernel time)
+            line["roofline"]["issue"] = {"valu_wave_instructions_per_launch": valu["wave_instructions_per_launch"],
+                                         "valu_wave_instructions_per_s": valu["wave_instructions_per_launch"] / (k_ms * 1e-3),
+                                         "valu_lane_instructions_per_auction": valu.get("valu_lane_instructions_per_auction")}
         profit_c, ideal, sc = D.unpack_metric_vector(totals, K)
         akncp, ncp = em.akncp_ncp_from_sums(profit_c / 100.0, ideal)
         line["episode_metric"] = {"AKNCP": akncp, "NCP": ncp, "profit_dollars": float(sc[0]) / 100.0,

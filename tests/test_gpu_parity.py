@@ -406,6 +406,14 @@ def test_max_keyword_counts(amd, K):
     _run_vs_oracle(amd, 1, K, planes, steps=1, budget=30.0)
 
 
+@pytest.mark.parametrize("K", [1500, 4096])
+def test_explicit_model_at_large_keyword_counts(amd, K):
+    """EXPLICIT: keyword-parallel pass, row walker (K = 1500: 81 KB of LDS) or, beyond its LDS, the serial walker"""
+    planes = H.explicit_params(1, K, seed=70 + K)
+    _run_vs_oracle(amd, 1, K, planes, steps=2, budget=1e9, model=1)
+    _run_vs_oracle(amd, 1, K, planes, steps=1, budget=900.0, model=1)
+
+
 def test_non_finite_inputs_do_not_break_the_step(amd):
     N, K = 2, 32
     planes = H.implicit_params(N, K, seed=61)
