@@ -16,7 +16,11 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 explicit = len(sys.argv) > 3 and sys.argv[3] == "explicit"      # the default-constructor (ExplicitKeyword) model
 t0 = time.time()
 cases = steps = reruns = 0
+last_report = t0
 while time.time() - t0 < budget_s:
+    if time.time() - last_report > 60:          # (a silent GPU job is taken for a hung one)
+        print(f"... {cases} engines, {steps} steps so far", flush=True)
+        last_report = time.time()
     N = int(rng.integers(1, 9))
     K = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 255, 256, 257, 300, 511, 700, 1024, 1100]))
     mv = float(rng.choice([0, 1, 5, 16, 40, 128, 600]))
