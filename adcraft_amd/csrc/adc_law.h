@@ -355,6 +355,19 @@ ADC_HD double cents_to_dollars_f64(int cents)
     return __builtin_fma(rem, 0.01, q0);
 }
 
+// (float)cents / 100.0f - the float32 dollars every observation is handed over in - without the division sequence
+// while |cents| < 2^24 (the same Markstein step as above, equal to the IEEE quotient for every such value: checked
+// exhaustively by tests/test_oracle_scalar.py::test_cents_to_dollars_is_the_ieee_quotient); larger amounts divide.
+ADC_HD float cents_to_dollars_f32(long long cents)
+{
+    const float a = (float)cents;
+    if (cents > -16777216ll && cents < 16777216ll) {
+        const float q0 = a * 0.01f;
+        return fma32(fma32(-q0, 100.0f, a), 0.01f, q0);
+    }
+    return a / 100.0f;
+}
+
 ADC_HD float clamp01(float v) { v = v > 0.0f ? v : 0.0f; return v < 1.0f ? v : 1.0f; }
 
 ADC_HD float threshold_sigmoid_f32(float bid, float thresh, float intercept, float slope)

@@ -304,6 +304,20 @@ ORC_API int64_t orc_check_div100(int64_t lo, int64_t hi)
     return bad;
 }
 
+/* the same for float32: q0 = c*0.01f; q = fmaf(fmaf(-q0,100,c), 0.01f, q0) vs (float)c / 100.0f, for |c| in [lo, hi) */
+ORC_API int64_t orc_check_div100f(int64_t lo, int64_t hi)
+{
+    int64_t bad = 0;
+    for (int64_t c = lo; c < hi; ++c) {
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+            const float a = (float)(sgn * c), q0 = a * 0.01f;
+            const float q = fmaf(fmaf(-q0, 100.0f, a), 0.01f, q0);
+            if (q != a / 100.0f) ++bad;
+        }
+    }
+    return bad;
+}
+
 ORC_API int64_t orc_budget_cents(float budget)
 {
     double c = rint((double)budget * 100.0);

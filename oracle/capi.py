@@ -83,6 +83,8 @@ def lib():
         L.orc_volume_from_word.argtypes = [C.c_uint32, C.c_float, C.c_float]
         L.orc_bid_cents.restype = C.c_int64
         L.orc_bid_cents.argtypes = [C.c_float]
+        L.orc_check_div100f.restype = C.c_int64
+        L.orc_check_div100f.argtypes = [C.c_int64, C.c_int64]
         L.orc_check_div100.restype = C.c_int64
         L.orc_check_div100.argtypes = [C.c_int64, C.c_int64]
         L.orc_budget_cents.restype = C.c_int64

@@ -214,3 +214,4 @@ def test_cents_to_dollars_is_the_ieee_quotient():
     need it equal to c / 100.0 for every cost that can occur."""
     assert L.orc_check_div100(0, 1 << 26) == 0
     assert L.orc_check_div100((1 << 31) - (1 << 22), 1 << 31) == 0
+    assert L.orc_check_div100f(0, 1 << 24) == 0            # cents_to_dollars_f32: every |cents| below 2^24, both signs
