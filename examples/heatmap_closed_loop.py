@@ -3,7 +3,8 @@
 (adcraft/baseline_experiment_and_figs_notebooks/run_heatmap_experiments.ipynb cells 1-4), device-resident.
 
 The notebook runs, for every (mean_volume, conversion_rate) cell, env seeds 5..8 x agent seeds 0..3 one after the
-other: reset(seed), sample the bid curves of the 100 keywords, then 60 days of NaiveZeroMarginStrategy with drift, and
+other: reset(seed), sample the bid curves of the 100 keywords, then 60 days of NaiveZeroMarginStrategy (stationary
+keywords: the notebook passes updater_mask=None, for which update_keywords returns at once, gymnasium_kw_env.py:127-128), and
 stores kw_profits / ideal_profits.  Here the 16 (env seed, agent seed) runs of a cell are the 16 envs of ONE engine and
 a day is three kernel launches (agent, ideal profit, step) for all of them.
 
@@ -41,7 +42,7 @@ def main():
             for i, (es, _) in enumerate(runs):                           # env.reset(seed=env_seed): the reference's draws
                 rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(es)))
                 planes[:, i] = utils.implicit_params_to_planes(utils.sample_implicit_keyword_params(K, rng, cfg))
-            eng = StepEngine(N, K, max_days=args.days, loss_threshold=10000.0, drift=(0.03, 0.03, 0.03), drift_enabled=True)
+            eng = StepEngine(N, K, max_days=args.days, loss_threshold=10000.0, drift_enabled=False)
             eng.set_all_params(planes)
             eng.reset(seeds=np.array([1000 * es + ag for es, ag in runs], dtype=np.uint64))
             r = run_baseline_episode(eng, args.policy, steps=args.days, budget=100000.0, default_rpc=1.0,

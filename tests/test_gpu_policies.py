@@ -193,3 +193,44 @@ def test_run_days_graph_replay_equals_single_steps(amd, model):
             assert np.array_equal(a[0][k], b[0][k]), k
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
+
+
+def test_heatmap_cells_match_the_reference_end_to_end(amd, golden):
+    """G11: cells of the paper's heat-map experiment run by the reference itself (its env, its agent, its metrics, the
+    notebook's loop).  The device-resident loop on the same keyword sets (reset(seed) generation is bit-exact) must give
+    the same mean AKNCP / NCP / profit per cell within the run-to-run noise: z-test on the difference of cell means."""
+    from adcraft_amd import gymnasium_kw_utils as utils
+    from adcraft_amd.closed_loop import run_baseline_episode
+    for cell in golden("g11_heatmap_cells.json")["cells"]:
+        K, days = cell["K"], cell["days"]
+        cfg = utils.experiment_keyword_config(cell["mean_volume"], cell["cvr"])
+        env_seeds = sorted(int(s) for s in cell["keyword_params"])
+        reps = 16                                        # engine runs per env seed (the reference has 4)
+        N = len(env_seeds) * reps
+        planes = np.zeros((8, N, K), np.float32)
+        for i, es in enumerate(env_seeds):
+            rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(es)))
+            raw = utils.sample_implicit_keyword_params(K, rng, cfg)
+            printed = utils.printed_params(raw, implicit=True)
+            got = [[[float(p[0][0]), float(p[0][1])]] + [float(x) for x in p[1:]] for p in printed]
+            assert got == cell["keyword_params"][str(es)]              # the very keyword set the reference ran on
+            planes[:, i * reps:(i + 1) * reps] = utils.implicit_params_to_planes(raw)[:, None, :]
+        e = amd.StepEngine(N, K, seed=77, max_days=days, loss_threshold=10000.0, drift_enabled=False)
+        e.set_all_params(planes)
+        e.reset(seeds=np.arange(N, dtype=np.uint64) + 1000)
+        r = run_baseline_episode(e, "zero_margin", steps=days, budget=100000.0, default_rpc=1.0,
+                                 agent_seeds=np.arange(N, dtype=np.uint64))
+        e.close()
+        ref = cell["runs"]
+        assert all(x["days"] == days for x in ref)
+        for name, mine in (("AKNCP", r["AKNCP"]), ("NCP", r["NCP"]), ("total_profit", r["kw_profit_sum"].sum(axis=1))):
+            theirs = np.array([x[name] for x in ref])
+            se = np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
+            z = (mine.mean() - theirs.mean()) / se
+            assert abs(z) < 4.0, (cell["mean_volume"], cell["cvr"], name, float(mine.mean()), float(theirs.mean()), float(z))
+        # the ideal profit is a property of the keyword set alone (same env seed -> same expected optimum, up to the
+        # 2048-sample estimator's noise)
+        for i, es in enumerate(env_seeds):
+            theirs = np.mean([x["total_ideal"] for x in ref if x["env_seed"] == es])
+            mine = r["ideal_sum"][i * reps:(i + 1) * reps].sum(axis=1).mean()
+            assert abs(mine / theirs - 1.0) < 0.05, (es, mine, theirs)

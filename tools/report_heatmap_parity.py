@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Prints, per G11 cell, the reference's and the engine's mean AKNCP / NCP / profit (same computation as
+tests/test_gpu_policies.py::test_heatmap_cells_match_the_reference_end_to_end)."""
+import json
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from adcraft_amd import gymnasium_kw_utils as utils  # noqa: E402
+from adcraft_amd.closed_loop import run_baseline_episode  # noqa: E402
+from adcraft_amd.engine import StepEngine  # noqa: E402
+
+g = json.load(open("tests/golden/g11_heatmap_cells.json"))
+print(f"{'volume':>7} {'cvr':>5} | {'AKNCP ref':>16} {'AKNCP engine':>16} {'z':>6} | {'NCP ref':>14} {'NCP engine':>14} {'z':>6} | profit ref / engine")
+for cell in g["cells"]:
+    K, days = cell["K"], cell["days"]
+    cfg = utils.experiment_keyword_config(cell["mean_volume"], cell["cvr"])
+    env_seeds = sorted(int(s) for s in cell["keyword_params"])
+    reps = 64
+    N = len(env_seeds) * reps
+    planes = np.zeros((8, N, K), np.float32)
+    for i, es in enumerate(env_seeds):
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(es)))
+        planes[:, i * reps:(i + 1) * reps] = utils.implicit_params_to_planes(utils.sample_implicit_keyword_params(K, rng, cfg))[:, None, :]
+    e = StepEngine(N, K, seed=78, max_days=days, loss_threshold=10000.0, drift_enabled=False)
+    e.set_all_params(planes)
+    e.reset(seeds=np.arange(N, dtype=np.uint64) + 5000)
+    r = run_baseline_episode(e, "zero_margin", steps=days, budget=100000.0, default_rpc=1.0, agent_seeds=np.arange(N, dtype=np.uint64))
+    e.close()
+    row = []
+    for name, mine in (("AKNCP", r["AKNCP"]), ("NCP", r["NCP"]), ("total_profit", r["kw_profit_sum"].sum(axis=1))):
+        theirs = np.array([x[name] for x in cell["runs"]])
+        z = (mine.mean() - theirs.mean()) / np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
+        row.append((theirs.mean(), theirs.std(ddof=1), mine.mean(), mine.std(ddof=1), z))
+    a, n, p = row
+    print(f"{cell['mean_volume']:7g} {cell['cvr']:5.2f} | {a[0]:7.3f} ±{a[1]:6.3f} {a[2]:8.3f} ±{a[3]:6.3f} {a[4]:6.2f} | "
+          f"{n[0]:6.3f} ±{n[1]:5.3f} {n[2]:7.3f} ±{n[3]:5.3f} {n[4]:6.2f} | {p[0]:9.1f} / {p[2]:9.1f} (z {p[4]:.2f})")
+print("reference: 16 runs per cell (4 env seeds x 4 agent seeds, tools/gen_golden_heatmap.py); engine: 256 runs per cell on the same 4 keyword sets")
