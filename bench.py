@@ -153,7 +153,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "env-steps/sec (envs x keywords auctions/s)",
+            "metric": "env-steps/sec (envs\u00d7keywords auctions/s)",
             "value": units / elapsed,
             "unit": "keyword-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
