@@ -220,14 +220,18 @@ def test_heatmap_cells_match_the_reference_end_to_end(amd, golden):
         e.reset(seeds=np.arange(N, dtype=np.uint64) + 1000)
         r = run_baseline_episode(e, "zero_margin", steps=days, budget=100000.0, default_rpc=1.0,
                                  agent_seeds=np.arange(N, dtype=np.uint64))
+        # the oracle bidder on the same keyword sets (run_oracle_agent, 300-point grid)
+        e.reset(seeds=np.arange(N, dtype=np.uint64) + 9000)
+        ro = run_baseline_episode(e, "oracle", steps=days, budget=100000.0, bid_grid=np.arange(0.01, 3.01, 0.01))
         e.close()
+        for ref, res, who in ((cell["runs"], r, "zero_margin"), (cell["oracle_runs"], ro, "oracle")):
+            assert all(x["days"] == days for x in ref)
+            for name, mine in (("AKNCP", res["AKNCP"]), ("NCP", res["NCP"]), ("total_profit", res["kw_profit_sum"].sum(axis=1))):
+                theirs = np.array([x[name] for x in ref])
+                se = np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
+                z = (mine.mean() - theirs.mean()) / se
+                assert abs(z) < 4.0, (cell["mean_volume"], cell["cvr"], who, name, float(mine.mean()), float(theirs.mean()), float(z))
         ref = cell["runs"]
-        assert all(x["days"] == days for x in ref)
-        for name, mine in (("AKNCP", r["AKNCP"]), ("NCP", r["NCP"]), ("total_profit", r["kw_profit_sum"].sum(axis=1))):
-            theirs = np.array([x[name] for x in ref])
-            se = np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
-            z = (mine.mean() - theirs.mean()) / se
-            assert abs(z) < 4.0, (cell["mean_volume"], cell["cvr"], name, float(mine.mean()), float(theirs.mean()), float(z))
         # the ideal profit is a property of the keyword set alone (same env seed -> same expected optimum, up to the
         # 2048-sample estimator's noise)
         for i, es in enumerate(env_seeds):

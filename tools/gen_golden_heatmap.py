@@ -56,6 +56,24 @@ def run_zero_margin_agent(agent, env, irs, cpcs, m, budget=100000):
     return np.array(kw_profits), np.array(ideal_profits)
 
 
+def run_oracle_agent(env, irs, cpcs, m, allowed_bids, budget=100000):
+    """timing_and_other_one_off_experiments.ipynb cell 2 (after env.reset(seed) by the caller)"""
+    previous_observation, info = env.reset()
+    truncated, terminated = False, False
+    kw_profits, ideal_profits = [], []
+    while not (terminated or truncated):
+        ideal_profit, kw_actions = [], []
+        for kw_index, kw_params in enumerate(env.keyword_params):
+            max_exp_profit, _, optimal_bid_index = m.get_max_expected_bid_profits(kw_params, cpcs[kw_index], irs[kw_index])
+            kw_actions.append(allowed_bids[optimal_bid_index])
+            ideal_profit.append(max_exp_profit)
+        ideal_profits.append(ideal_profit)
+        previous_observation, reward, terminated, truncated, info = env.step(
+            action={"budget": budget, "keyword_bids": np.array(kw_actions)})
+        kw_profits.append(previous_observation["revenue"] - previous_observation["cost"])
+    return np.array(kw_profits), np.array(ideal_profits)
+
+
 def main():
     warnings.filterwarnings("ignore")
     rust = G.install_standins()
@@ -88,7 +106,22 @@ def main():
                                  NCP=float(m.compute_NCP(kw_profits, ideal_profits)), total_profit=float(kw_profits.sum()),
                                  total_ideal=float(ideal_profits.sum()), days=int(kw_profits.shape[0])))
                 print(cell, runs[-1], f"{time.time() - t0:.0f} s", flush=True)
-        out.append(dict(cell, K=K, days=DAYS, runs=runs, keyword_params=params_by_seed))
+        oracle_runs = []
+        for env_seed in ENV_SEEDS:
+            for rep in range(2):
+                env.reset(seed=env_seed)
+                allowed_bids = np.arange(0.01, 3.01, 0.01)               # the oracle notebook's grid (300 points)
+                irs, cpcs = [], []
+                for kw in env.keywords:
+                    ir, cpc = m.get_implicit_kw_bid_cpc_impressions(kw, allowed_bids)
+                    irs.append(ir)
+                    cpcs.append(cpc)
+                kw_profits, ideal_profits = run_oracle_agent(env, irs, cpcs, m, allowed_bids)
+                oracle_runs.append(dict(env_seed=env_seed, AKNCP=float(m.compute_AKNCP(kw_profits, ideal_profits)),
+                                        NCP=float(m.compute_NCP(kw_profits, ideal_profits)), total_profit=float(kw_profits.sum()),
+                                        total_ideal=float(ideal_profits.sum()), days=int(kw_profits.shape[0])))
+                print(cell, "oracle", oracle_runs[-1], f"{time.time() - t0:.0f} s", flush=True)
+        out.append(dict(cell, K=K, days=DAYS, runs=runs, oracle_runs=oracle_runs, keyword_params=params_by_seed))
     path = os.path.join(G.OUT, "g11_heatmap_cells.json")
     with open(path, "w") as f:
         json.dump(dict(source="run_heatmap_experiments.ipynb cells 1-4 on the reference's own env, agent and metrics "
