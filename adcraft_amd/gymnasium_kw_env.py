@@ -249,8 +249,9 @@ class BiddingSimulation(_EnvBase):
         bid_array = action.get("keyword_bids")
         self.budget = np.round(budget_array, 2).astype(float)                                # :199
         bids64 = np.asarray(bid_array, dtype=np.float64).reshape(self.num_keywords)
-        bids = [float(b) for b in np.round(np.maximum(bids64, 0.01), 2)]                     # :215 (f64: B-9)
-        out = self._engine.step(np.asarray(bids, dtype=np.float32)[None, :],
+        rounded = np.round(np.maximum(bids64, 0.01), 2)                                      # :215 (f64: B-9)
+        bids = rounded.tolist()
+        out = self._engine.step(rounded.astype(np.float32)[None, :],
                                 np.float32(np.asarray(self.budget, dtype=np.float64).reshape(-1)[0]), copy=False)
         profits = float(out["reward"][0])
         self.cumulative_profit = float(out["cumulative_profit"][0])
@@ -268,7 +269,7 @@ class BiddingSimulation(_EnvBase):
             days_passed=np.array([self.current_day], dtype=np.float32))
         if self._drift_on():
             self._params_dirty = True            # update_keywords() ran on the device (:246)
-        snap = {k: v.copy() for k, v in observations.items()}
+        snap = dict(observations)            # (the arrays are this step's own copies; formatted only if somebody looks)
         info = {
             "bids": bids,
             "bidding_outcomes": _Lazy(lambda: self._repr_outcomes(bids, snap)),
