@@ -215,12 +215,14 @@ def test_heatmap_cells_match_the_reference_end_to_end(amd, golden):
             got = [[[float(p[0][0]), float(p[0][1])]] + [float(x) for x in p[1:]] for p in printed]
             assert got == cell["keyword_params"][str(es)]              # the very keyword set the reference ran on
             planes[:, i * reps:(i + 1) * reps] = utils.implicit_params_to_planes(raw)[:, None, :]
-        e = amd.StepEngine(N, K, seed=77, max_days=days, loss_threshold=10000.0, drift_enabled=False)
+        e = amd.StepEngine(N, K, seed=77, max_days=days, loss_threshold=10000.0, drift_enabled=bool(cell.get("drift")),
+                           drift=(0.03, 0.03, 0.03))
         e.set_all_params(planes)
         e.reset(seeds=np.arange(N, dtype=np.uint64) + 1000)
         r = run_baseline_episode(e, "zero_margin", steps=days, budget=100000.0, default_rpc=1.0,
                                  agent_seeds=np.arange(N, dtype=np.uint64))
         # the oracle bidder on the same keyword sets (run_oracle_agent, 300-point grid)
+        e.set_all_params(planes)                          # (a drift cell: every reference run starts from the fresh keyword set)
         e.reset(seeds=np.arange(N, dtype=np.uint64) + 9000)
         ro = run_baseline_episode(e, "oracle", steps=days, budget=100000.0, bid_grid=np.arange(0.01, 3.01, 0.01))
         e.close()
@@ -228,13 +230,16 @@ def test_heatmap_cells_match_the_reference_end_to_end(amd, golden):
             assert all(x["days"] == days for x in ref)
             for name, mine in (("AKNCP", res["AKNCP"]), ("NCP", res["NCP"]), ("total_profit", res["kw_profit_sum"].sum(axis=1))):
                 theirs = np.array([x[name] for x in ref])
-                se = np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
+                # under the hypothesis tested both samples have the same per-run spread; the engine's many runs estimate
+                # it far better than the reference's 8 or 16 (whose sample variance alone makes a fragile z)
+                se = mine.std(ddof=1) * np.sqrt(1.0 / theirs.size + 1.0 / mine.size)
                 z = (mine.mean() - theirs.mean()) / se
-                assert abs(z) < 4.0, (cell["mean_volume"], cell["cvr"], who, name, float(mine.mean()), float(theirs.mean()), float(z))
+                assert abs(z) < 4.0, (cell["mean_volume"], cell["cvr"], cell.get("drift"), who, name, float(mine.mean()), float(theirs.mean()), float(z))
         ref = cell["runs"]
         # the ideal profit is a property of the keyword set alone (same env seed -> same expected optimum, up to the
         # 2048-sample estimator's noise)
         for i, es in enumerate(env_seeds):
             theirs = np.mean([x["total_ideal"] for x in ref if x["env_seed"] == es])
             mine = r["ideal_sum"][i * reps:(i + 1) * reps].sum(axis=1).mean()
-            assert abs(mine / theirs - 1.0) < 0.05, (es, mine, theirs)
+            # (a drift cell: the ideal follows each run's own random walk of the parameters, so the 4-run mean is noisier)
+            assert abs(mine / theirs - 1.0) < (0.15 if cell.get("drift") else 0.05), (es, mine, theirs)

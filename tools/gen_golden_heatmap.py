@@ -22,7 +22,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_golden as G  # noqa: E402
 
-CELLS = [dict(mean_volume=16, cvr=0.67), dict(mean_volume=128, cvr=0.34), dict(mean_volume=4, cvr=1.0)]
+# drift=True: the non-stationary experiment (timing_and_other_one_off_experiments.ipynb cell 3: updater_mask all True)
+CELLS = [dict(mean_volume=16, cvr=0.67, drift=False), dict(mean_volume=128, cvr=0.34, drift=False),
+         dict(mean_volume=4, cvr=1.0, drift=False), dict(mean_volume=16, cvr=0.67, drift=True)]
 ENV_SEEDS, AGENT_SEEDS = (5, 6, 7, 8), (0, 1, 2, 3)
 K, DAYS = 100, 60
 
@@ -85,13 +87,18 @@ def main():
     out = []
     for cell in CELLS:
         cfg, _ = G.quant_cfg(eq, cell["mean_volume"], cell["cvr"])
-        env = kw_sim.bidding_sim_creator(env_config=dict(
-            keyword_config=cfg, num_keywords=K, max_days=DAYS,
-            updater_params=[["vol", 0.03], ["ctr", 0.03], ["cvr", 0.03]], updater_mask=None))
+
+        def make_env():
+            return kw_sim.bidding_sim_creator(env_config=dict(
+                keyword_config=cfg, num_keywords=K, max_days=DAYS,
+                updater_params=[["vol", 0.03], ["ctr", 0.03], ["cvr", 0.03]], updater_mask=[True] * K if cell["drift"] else None))
+        env = make_env()
         runs, params_by_seed = [], {}
         t0 = time.time()
         for env_seed in ENV_SEEDS:
             for agent_seed in AGENT_SEEDS:
+                if cell["drift"]:
+                    env = make_env()         # as get_nonstationary_profits does (init_volumes belong to this keyword set)
                 env.reset(seed=env_seed)
                 params_by_seed[str(env_seed)] = G.params_to_json(env.keyword_params)
                 allowed_bids = np.arange(0.01, 3.00, 0.01)
@@ -109,6 +116,8 @@ def main():
         oracle_runs = []
         for env_seed in ENV_SEEDS:
             for rep in range(2):
+                if cell["drift"]:
+                    env = make_env()
                 env.reset(seed=env_seed)
                 allowed_bids = np.arange(0.01, 3.01, 0.01)               # the oracle notebook's grid (300 points)
                 irs, cpcs = [], []
@@ -125,7 +134,8 @@ def main():
     path = os.path.join(G.OUT, "g11_heatmap_cells.json")
     with open(path, "w") as f:
         json.dump(dict(source="run_heatmap_experiments.ipynb cells 1-4 on the reference's own env, agent and metrics "
-                              "(stationary keywords: updater_mask=None, gymnasium_kw_env.py:127-128)", cells=out), f)
+                              "(stationary keywords: updater_mask=None, gymnasium_kw_env.py:127-128; drift cells: updater_mask all True, "
+                              "timing_and_other_one_off_experiments.ipynb cell 3)", cells=out), f)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 

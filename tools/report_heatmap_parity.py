@@ -24,27 +24,29 @@ for cell in g["cells"]:
     for i, es in enumerate(env_seeds):
         rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(es)))
         planes[:, i * reps:(i + 1) * reps] = utils.implicit_params_to_planes(utils.sample_implicit_keyword_params(K, rng, cfg))[:, None, :]
-    e = StepEngine(N, K, seed=78, max_days=days, loss_threshold=10000.0, drift_enabled=False)
+    e = StepEngine(N, K, seed=78, max_days=days, loss_threshold=10000.0, drift_enabled=bool(cell.get("drift")), drift=(0.03, 0.03, 0.03))
     e.set_all_params(planes)
     e.reset(seeds=np.arange(N, dtype=np.uint64) + 5000)
     r = run_baseline_episode(e, "zero_margin", steps=days, budget=100000.0, default_rpc=1.0, agent_seeds=np.arange(N, dtype=np.uint64))
+    e.set_all_params(planes)
     e.reset(seeds=np.arange(N, dtype=np.uint64) + 9000)
     ro = run_baseline_episode(e, "oracle", steps=days, budget=100000.0, bid_grid=np.arange(0.01, 3.01, 0.01))
     e.close()
     orow = []
     for name, mine in (("AKNCP", ro["AKNCP"]), ("NCP", ro["NCP"]), ("total_profit", ro["kw_profit_sum"].sum(axis=1))):
         theirs = np.array([x[name] for x in cell["oracle_runs"]])
-        z = (mine.mean() - theirs.mean()) / np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
+        z = (mine.mean() - theirs.mean()) / (mine.std(ddof=1) * np.sqrt(1.0 / theirs.size + 1.0 / mine.size))
         orow.append((theirs.mean(), mine.mean(), z))
-    oracle_lines.append(f"{cell['mean_volume']:7g} {cell['cvr']:5.2f} | oracle bidder: AKNCP {orow[0][0]:.3f} / {orow[0][1]:.3f} (z {orow[0][2]:.2f})  "
+    oracle_lines.append(f"{cell['mean_volume']:7g} {cell['cvr']:5.2f}{' drift' if cell.get('drift') else ''} | oracle bidder: AKNCP {orow[0][0]:.3f} / {orow[0][1]:.3f} (z {orow[0][2]:.2f})  "
                         f"NCP {orow[1][0]:.3f} / {orow[1][1]:.3f} (z {orow[1][2]:.2f})  profit {orow[2][0]:.1f} / {orow[2][1]:.1f} (z {orow[2][2]:.2f})")
     row = []
     for name, mine in (("AKNCP", r["AKNCP"]), ("NCP", r["NCP"]), ("total_profit", r["kw_profit_sum"].sum(axis=1))):
         theirs = np.array([x[name] for x in cell["runs"]])
-        z = (mine.mean() - theirs.mean()) / np.sqrt(theirs.var(ddof=1) / theirs.size + mine.var(ddof=1) / mine.size)
+        z = (mine.mean() - theirs.mean()) / (mine.std(ddof=1) * np.sqrt(1.0 / theirs.size + 1.0 / mine.size))
         row.append((theirs.mean(), theirs.std(ddof=1), mine.mean(), mine.std(ddof=1), z))
     a, n, p = row
-    print(f"{cell['mean_volume']:7g} {cell['cvr']:5.2f} | {a[0]:7.3f} ±{a[1]:6.3f} {a[2]:8.3f} ±{a[3]:6.3f} {a[4]:6.2f} | "
+    print(f"{cell['mean_volume']:7g} {cell['cvr']:5.2f}{'*' if cell.get('drift') else ' '}| {a[0]:7.3f} ±{a[1]:6.3f} {a[2]:8.3f} ±{a[3]:6.3f} {a[4]:6.2f} | "
           f"{n[0]:6.3f} ±{n[1]:5.3f} {n[2]:7.3f} ±{n[3]:5.3f} {n[4]:6.2f} | {p[0]:9.1f} / {p[2]:9.1f} (z {p[4]:.2f})")
 print("\n".join(oracle_lines))
+print("(* = non-stationary cell: updater_mask all True, drift 0.03 / 0.03 / 0.03)")
 print("reference: 16 runs per cell (4 env seeds x 4 agent seeds, tools/gen_golden_heatmap.py); engine: 256 runs per cell on the same 4 keyword sets; oracle bidder: reference / engine, 8 reference runs per cell")
