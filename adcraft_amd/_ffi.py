@@ -40,7 +40,8 @@ class Tape(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("volumes", "bid_cents", "x_impressions", "x_cost", "click", "conv", "rev_cents")]
                 + [(n, C.c_int64) for n in ("len_bid", "len_ximp", "len_xcost", "len_click", "len_conv", "len_rev")]
                 + [(n, C.c_void_p) for n in ("off_bid", "off_ximp", "off_xcost", "off_click", "off_conv", "off_rev")]
-                + [(n, C.c_void_p) for n in ("end_bid", "end_ximp", "end_xcost", "end_click", "end_conv", "end_rev")])
+                + [(n, C.c_void_p) for n in ("end_bid", "end_ximp", "end_xcost", "end_click", "end_conv", "end_rev")]
+                + [("drift_uniforms", C.c_void_p)])
 
 
 _lib = None
@@ -129,7 +130,7 @@ def lib():
         fn = getattr(L, name)      # AttributeError here = the .so does not export what the header declares
         fn.argtypes = args
         fn.restype = res
-    if L.adc_abi_version() != 1:
+    if L.adc_abi_version() != 2:
         raise EngineError("libadcraft_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -336,7 +336,7 @@ class ReplayTape:
     """Host-side tape for StepEngine.step_replay: the variates the reference drew, in its order."""
 
     def __init__(self, num_envs, volumes, bid_cents=(), click=(), conv=(), rev_cents=(), x_impressions=(), x_cost=(),
-                 offsets=None):
+                 offsets=None, drift_uniforms=None):
         N = int(num_envs)
         self.vol = np.ascontiguousarray(volumes, dtype=np.int32)
         self.bid = np.ascontiguousarray(bid_cents, dtype=np.int32)
@@ -353,4 +353,9 @@ class ReplayTape:
             self.vol.ctypes.data, self.bid.ctypes.data, self.ximp.ctypes.data, self.xcost.ctypes.data,
             self.click.ctypes.data, self.conv.ctypes.data, self.rev.ctypes.data,
             self.bid.size, self.ximp.size, self.xcost.size, self.click.size, self.conv.size, self.rev.size,
-            *(self.off[n].ctypes.data for n in names), *(self.end[n].ctypes.data for n in names))
+            *(self.off[n].ctypes.data for n in names), *(self.end[n].ctypes.data for n in names), None)
+        # the three vectors update_keywords() drew after this step (vol, ctr, cvr; gymnasium_kw_env.py:132-135), [3][N][K]
+        self.drift = None if drift_uniforms is None else np.ascontiguousarray(drift_uniforms, dtype=np.float32)
+        if self.drift is not None:
+            assert self.drift.size == 3 * self.vol.size, "drift_uniforms must be [3][num_envs][num_keywords]"
+            self.struct.drift_uniforms = self.drift.ctypes.data

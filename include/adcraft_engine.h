@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADC_ABI_VERSION 1
+#define ADC_ABI_VERSION 2
 
 typedef enum adc_status {
     ADC_OK = 0,
@@ -130,6 +130,10 @@ typedef struct adc_tape {
     int64_t len_bid, len_ximp, len_xcost, len_click, len_conv, len_rev;  /* tape lengths (bounds checks) */
     const int64_t *off_bid, *off_ximp, *off_xcost, *off_click, *off_conv, *off_rev;   /* [N] start cursors */
     int64_t *end_bid, *end_ximp, *end_xcost, *end_click, *end_conv, *end_rev;         /* [N] nullable */
+    /* nullable [3][N*K]: the three coefficient vectors update_keywords() drew, np_random.uniform(-a, a, size=K) in its
+     * order vol, ctr, cvr (adcraft/gymnasium_kw_env.py:132-135).  When given (drift must be enabled) the replayed step ends
+     * with update_keywords() on exactly these coefficients (:246), applied at once instead of from the engine's stream. */
+    const float *drift_uniforms;
 } adc_tape;
 
 /* quantile tables for device-side keyword generation: the rows of the reference's quantile DataFrame, per quantity

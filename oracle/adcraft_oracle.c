@@ -420,6 +420,8 @@ typedef struct {             /* TAPE source: flat per-call tapes + cursors (adva
     const uint8_t *click, *conv;
     const int32_t *rev_cents;
     int64_t cur_bid, cur_ximp, cur_xcost, cur_click, cur_conv, cur_rev;  /* in/out */
+    const float *drift_uniforms; /* nullable [3][N][K]: the vectors np_random.uniform(-a, a, size=K) of update_keywords()
+                                  * in its order vol, ctr, cvr (gymnasium_kw_env.py:132-135); applied at the end of the step */
 } orc_tape;
 
 typedef struct {
@@ -463,6 +465,22 @@ static void apply_drift(const orc_config *c, orc_state *s, int env, uint32_t tic
         float us = fmaf(2.0f * c->drift_cvr, u24(w[2]), -c->drift_cvr);
         float *vm = Pp(s, c, P_VOL_MEAN, env, k), *bc = Pp(s, c, P_BCTR, env, k), *sc = Pp(s, c, P_SCTR, env, k);
         float sd0 = P(s, c, P_VOL_STD, env, k);      /* :136-137 "init volume" is the vol std */
+        *vm = fmaxf(fmaf(uv, sd0, *vm), 0.0f);       /* :146-149 */
+        *bc = fminf(fmaxf(*bc * (1.0f + uc), 0.0f), 1.0f);   /* :153-155 */
+        *sc = fminf(fmaxf(*sc * (1.0f + us), 0.0f), 1.0f);   /* :156-158 */
+    }
+}
+
+/* the same update with the three coefficient vectors supplied by the caller (TAPE mode): the step calls
+ * update_keywords() after the observation is formed (gymnasium_kw_env.py:246), so it is applied at once */
+static void apply_drift_tape(const orc_config *c, orc_state *s, int env, const float *u)
+{
+    const size_t NK = (size_t)c->num_envs * c->num_keywords;
+    for (int k = 0; k < c->num_keywords; ++k) {
+        const size_t i = (size_t)env * c->num_keywords + k;
+        const float uv = u[i], uc = u[NK + i], us = u[2 * NK + i];
+        float *vm = Pp(s, c, P_VOL_MEAN, env, k), *bc = Pp(s, c, P_BCTR, env, k), *sc = Pp(s, c, P_SCTR, env, k);
+        float sd0 = P(s, c, P_VOL_STD, env, k);      /* :136-137 */
         *vm = fmaxf(fmaf(uv, sd0, *vm), 0.0f);       /* :146-149 */
         *bc = fminf(fmaxf(*bc * (1.0f + uc), 0.0f), 1.0f);   /* :153-155 */
         *sc = fminf(fmaxf(*sc * (1.0f + us), 0.0f), 1.0f);   /* :156-158 */
@@ -659,6 +677,10 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
     o->terminated[env] = s->day[env] >= c->max_days;                /* :228 */
     s->tick[env] = tick + 1u;
     if (c->drift_on) s->drift_pending[env] = 1;                     /* :246 update_keywords() */
+    if (use_tape && c->drift_on && tape->drift_uniforms) {          /* TAPE: the recorded coefficients, at once */
+        apply_drift_tape(c, s, env, tape->drift_uniforms);
+        s->drift_pending[env] = 0;
+    }
     if (c->auto_reset && (o->terminated[env] || o->truncated[env])) {
         s->day[env] = 0; s->cum_cents[env] = 0; s->cum[env] = 0.0;  /* :327-328 */
     }

@@ -34,7 +34,8 @@ class Tape(C.Structure):
     _fields_ = [("volumes", C.c_void_p), ("bid_cents", C.c_void_p), ("x_impressions", C.c_void_p),
                 ("x_cost", C.c_void_p), ("click", C.c_void_p), ("conv", C.c_void_p), ("rev_cents", C.c_void_p),
                 ("cur_bid", C.c_int64), ("cur_ximp", C.c_int64), ("cur_xcost", C.c_int64),
-                ("cur_click", C.c_int64), ("cur_conv", C.c_int64), ("cur_rev", C.c_int64)]
+                ("cur_click", C.c_int64), ("cur_conv", C.c_int64), ("cur_rev", C.c_int64),
+                ("drift_uniforms", C.c_void_p)]
 
 
 class Out(C.Structure):
@@ -183,8 +184,14 @@ class TapeSource:
         self.ximp = np.ascontiguousarray(x_impressions, dtype=np.int32)
         self.xcost = np.ascontiguousarray(x_cost, dtype=np.float64)
         self.vol = None
+        self.drift = None
         self.struct = Tape(0, self.bid.ctypes.data, self.ximp.ctypes.data, self.xcost.ctypes.data,
-                           self.click.ctypes.data, self.conv.ctypes.data, self.rev.ctypes.data, 0, 0, 0, 0, 0, 0)
+                           self.click.ctypes.data, self.conv.ctypes.data, self.rev.ctypes.data, 0, 0, 0, 0, 0, 0, None)
+
+    def set_drift_uniforms(self, uniforms_3nk):
+        """the three vectors update_keywords() drew (vol, ctr, cvr), [3][N][K]; None = no drift after the step"""
+        self.drift = None if uniforms_3nk is None else np.ascontiguousarray(uniforms_3nk, dtype=np.float32)
+        self.struct.drift_uniforms = None if self.drift is None else self.drift.ctypes.data
 
     def set_volumes(self, volumes):
         self.vol = np.ascontiguousarray(volumes, dtype=np.int32)

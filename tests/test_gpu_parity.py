@@ -191,6 +191,73 @@ def test_g8_env_episodes_on_gpu(amd, golden):
         e.close()
 
 
+def test_g4_drift_replay_on_gpu(amd, golden):
+    """G4: update_keywords() of the reference (gymnasium_kw_env.py:114-158) replayed through k_step_exact<., TAPE>: the tape
+    carries the three uniform vectors the reference drew; the engine ends the replayed step with update_keywords() on exactly
+    those coefficients.  The engine holds parameters in float32, the reference in float64: each update is one f32 fma (volume)
+    or one f32 multiply + clip (rates), so after s steps the relative difference is at most about s * 2^-23.
+    Tolerance: rtol 2e-6 (+ atol 2e-6 for the volume, whose increments are ~0.03 * std)."""
+    for seq in golden("g4_update_keywords.json")["sequences"]:
+        K = seq["K"]
+        up = dict((n, v) for n, v in seq["updater_params"])
+        e = amd.StepEngine(1, K, seed=1, drift_enabled=True, drift=(up["vol"], up["ctr"], up["cvr"]))
+        p0 = seq["params0"]
+        planes = np.array([[p[0][0] for p in p0], [p[0][1] for p in p0], [p[1] for p in p0], [1.0 / p[2] for p in p0],
+                           [p[3] for p in p0], [p[4] for p in p0], [p[5] for p in p0], [p[6] for p in p0]], np.float32).reshape(8, 1, K)
+        e.set_all_params(planes)
+        e.reset()
+        for st in seq["steps"]:
+            tape = amd.ReplayTape(1, np.zeros((1, K), np.int32), drift_uniforms=np.array(st["uniforms"]).reshape(3, 1, K))
+            out = e.step_replay(np.full((1, K), 0.5, np.float32), 10.0, tape)
+            assert out["impressions"].sum() == 0 and out["reward"][0] == 0.0          # zero-volume day: nothing but the drift happens
+            got = e.get_all_params()[:, 0]
+            ref = st["params"]
+            np.testing.assert_allclose(got[0], [p[0][0] for p in ref], rtol=2e-6, atol=2e-6)
+            assert np.array_equal(got[1], planes[1, 0])                                 # vol std never changes (:146-149)
+            np.testing.assert_allclose(got[4], st["kw_bctr"], rtol=2e-6)
+            np.testing.assert_allclose(got[5], st["kw_sctr"], rtol=2e-6)
+            np.testing.assert_allclose(got[4], [p[3] for p in ref], rtol=2e-6)
+            np.testing.assert_allclose(got[5], [p[4] for p in ref], rtol=2e-6)
+        e.close()
+
+
+def test_drift_tape_matches_oracle_bitwise_and_needs_drift_enabled(amd):
+    """the HIP replay of a tape with drift coefficients == the C oracle's, bit for bit (both hold float32 parameters), on days
+    that also have auctions; a tape with drift coefficients on an engine without drift is refused"""
+    from oracle import capi as orc
+    K = 40
+    planes = H.implicit_params(1, K, seed=77, mean_volume=20)
+    rng = np.random.default_rng(5)
+    e = amd.StepEngine(1, K, seed=3, drift_enabled=True)
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes, drift_on=True)
+    for _ in range(3):
+        u = rng.uniform(-0.03, 0.03, (3, 1, K)).astype(np.float32)
+        vol = rng.integers(0, 30, (1, K)).astype(np.int32)
+        n = int(vol.sum())
+        comp = rng.integers(10, 120, n).astype(np.int32)
+        click = rng.integers(0, 2, n).astype(np.uint8)
+        conv = rng.integers(0, 2, n).astype(np.uint8)
+        rev = rng.integers(1, 300, n).astype(np.int32)
+        bids = rng.uniform(0.3, 1.0, (1, K)).astype(np.float32)
+        got = e.step_replay(bids, 1e9, amd.ReplayTape(1, vol, bid_cents=comp, click=click, conv=conv, rev_cents=rev, drift_uniforms=u))
+        ts = orc.TapeSource(bid_cents=comp, click=click, conv=conv, rev_cents=rev)
+        ts.set_volumes(vol)
+        ts.set_drift_uniforms(u)
+        ref = o.step(bids, 1e9, tape=ts)
+        H.assert_step_equal(got, ref)
+        assert np.array_equal(e.get_all_params(), o.params)          # drift applied at once on both sides, same float32 ops
+        assert not o.drift_pending.any()
+    assert not np.array_equal(o.params[0], planes[0])
+    e.close()
+    e2 = amd.StepEngine(1, 4, seed=3)          # drift not enabled
+    e2.reset()
+    with pytest.raises(ValueError, match="drift"):
+        e2.step_replay(np.full((1, 4), 0.5, np.float32), 1.0, amd.ReplayTape(1, np.zeros((1, 4), np.int32), drift_uniforms=np.zeros((3, 1, 4))))
+    e2.close()
+
+
 def test_g1_nth_price_auction_on_gpu(amd, golden):
     import ctypes as C
     from adcraft_amd import _ffi
@@ -259,44 +326,79 @@ def test_step_before_reset_raises(amd):
 
 
 # ------------------------------------------------------------------ BASELINE full size: size-independent properties
-def test_full_size_cfg2_properties(amd):
-    N, K = 4096, 256
-    planes = H.implicit_params(N, K, seed=1730)
-    e = amd.StepEngine(N, K, seed=1730)
+def _full_size_properties(amd, name, steps=1, seed=1730):
+    """One BASELINE config at its full per-GPU size: domain properties that do not depend on the size (click <= impression,
+    conversion <= click, no money without an event, the reward is the checksum of the per-keyword checksums), idempotence
+    (same stream state + same actions -> the identical step), and a 4-env slice of the big launch against the CPU oracle on
+    the same envs - for `steps` consecutive days (drift on where the config has it)."""
+    from adcraft_amd import synthetic
+    from oracle import capi as orc
+    N, K, mean_volume, cvr, no_vol_prob, drift = synthetic.CONFIGS[name]
+    planes = H.implicit_params(N, K, seed=seed, mean_volume=mean_volume, cvr=cvr, no_vol_prob=no_vol_prob)
+    e = amd.StepEngine(N, K, seed=seed, drift_enabled=drift)
     e.set_all_params(planes)
     e.reset()
     k0, t0 = e.get_rng_state()
-    e.sample_actions(0.3, 1.0, 1e9)
-    e.step_device()
-    a = e.fetch()
-    assert (a["buyside_clicks"] <= a["impressions"]).all()
-    assert (a["sellside_conversions"] <= a["buyside_clicks"]).all()
-    assert (a["cost"][a["buyside_clicks"] == 0] == 0).all() and (a["revenue"][a["sellside_conversions"] == 0] == 0).all()
-    assert (a["impressions"] <= 128 + 6 * 65).all() and a["impressions"].mean() > 20
-    cents = np.rint(a["revenue"].astype(np.float64) * 100) - np.rint(a["cost"].astype(np.float64) * 100)
-    assert np.array_equal(np.rint(a["reward"] * 100), cents.sum(axis=1))          # checksum of checksums
-    assert (a["days_passed"] == 1).all() and not a["terminated"].any()
-    # idempotence: same stream state + same actions -> identical step
-    e.set_rng_state(k0, t0)
-    e.set_episode_state(np.zeros(N, np.int32), np.zeros(N))
-    e.sample_actions(0.3, 1.0, 1e9)
-    e.step_device()
-    b = e.fetch()
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
-    # a slice of the big launch equals the oracle on the same envs
-    sub = slice(100, 104)
-    e.set_rng_state(k0, t0)
-    from oracle import capi as orc
-    o = orc.OracleEngine(4, K)
+    sub = slice(N // 3, N // 3 + 4)
+    o = orc.OracleEngine(4, K, drift_on=drift)
     o.params[:] = planes[:, sub]
     o.key[:] = k0[sub]
     o.tick[:] = t0[sub]
-    ref = o.step(o.sample_bids(0.3, 1.0), 1e9)
-    assert np.array_equal(a["impressions"][sub], ref["impressions"])
-    assert np.array_equal(a["buyside_clicks"][sub], ref["clicks"])
-    assert np.array_equal(a["reward"][sub], ref["reward"])
+    first = None
+    vmax = mean_volume + 6 * (1 + mean_volume // 2)
+    for s in range(steps):
+        e.sample_actions(0.3, 1.0, 1e9)
+        e.step_device()
+        a = e.fetch()
+        if first is None:
+            first = a
+        assert (a["buyside_clicks"] <= a["impressions"]).all()
+        assert (a["sellside_conversions"] <= a["buyside_clicks"]).all()
+        assert (a["cost"][a["buyside_clicks"] == 0] == 0).all() and (a["revenue"][a["sellside_conversions"] == 0] == 0).all()
+        assert (a["impressions"] <= vmax * (1.0 + 0.2 * s)).all()
+        assert a["impressions"].mean() > 0.12 * mean_volume * (1.0 - no_vol_prob)
+        if no_vol_prob > 0:
+            assert (a["impressions"][planes[0] == 0] <= 3).all()       # volume ~ N(0, U*0.5) clipped at 0: a rare auction or two
+        cents = np.rint(a["revenue"].astype(np.float64) * 100) - np.rint(a["cost"].astype(np.float64) * 100)
+        assert np.array_equal(np.rint(a["reward"] * 100), cents.sum(axis=1))          # checksum of checksums
+        assert (a["days_passed"] == s + 1).all() and not a["terminated"].any()
+        ref = o.step(o.sample_bids(0.3, 1.0), 1e9)
+        H.assert_step_equal({k: v[sub] for k, v in a.items()}, ref)
+    if drift:
+        o.materialize_drift()
+        got = e.get_all_params()
+        assert np.array_equal(got[:, sub], o.params)
+        assert not np.array_equal(got[0], planes[0])
+    else:
+        # idempotence: same stream state + same actions -> identical step
+        e.set_rng_state(k0, t0)
+        e.set_episode_state(np.zeros(N, np.int32), np.zeros(N))
+        e.sample_actions(0.3, 1.0, 1e9)
+        e.step_device()
+        b = e.fetch()
+        for k in first:
+            assert np.array_equal(first[k], b[k]), k
     e.close()
+
+
+def test_full_size_cfg2_properties(amd):
+    """BASELINE configs[1]: 4096 envs x 256 keywords, dense stationary"""
+    _full_size_properties(amd, "cfg2")
+
+
+def test_full_size_cfg3_properties(amd):
+    """BASELINE configs[2]: 16384 envs x 1024 keywords, sparse volume (half the keywords empty, mean volume 16, cvr 0.1)"""
+    _full_size_properties(amd, "cfg3")
+
+
+def test_full_size_cfg4_shard_properties(amd):
+    """BASELINE configs[3]: the per-GPU shard (8192 x 1024) of 65536 x 1024 over 8 GPUs"""
+    _full_size_properties(amd, "cfg4")
+
+
+def test_full_size_cfg5_shard_properties_with_drift(amd):
+    """BASELINE configs[4]: the per-GPU shard (2048 x 1024) of 16384 x 1024 with CTR/CVR/volume drift, three days"""
+    _full_size_properties(amd, "cfg5", steps=3)
 
 
 # ------------------------------------------------------------------ metrics on the device

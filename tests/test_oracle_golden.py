@@ -134,6 +134,33 @@ def test_g4_update_keywords(golden):
             assert got == st["params"]
 
 
+def test_g4_update_keywords_through_the_c_oracle_tape(golden):
+    """G4 replayed by oracle/adcraft_oracle.c itself (not only the f64 numpy restatement): the tape carries the three
+    uniform vectors, the replayed zero-volume day ends with update_keywords() on them.  The C oracle (like the HIP engine)
+    holds parameters in float32: one f32 fma / multiply + clip per update, so the difference from the reference's float64
+    after s steps is bounded by about s * 2^-23 relative.  Tolerance: rtol 2e-6 (+ atol 2e-6 on the volume)."""
+    for seq in golden("g4_update_keywords.json")["sequences"]:
+        K = seq["K"]
+        up = dict((n, v) for n, v in seq["updater_params"])
+        o = orc.OracleEngine(1, K, drift=(up["vol"], up["ctr"], up["cvr"]), drift_on=True)
+        p0 = seq["params0"]
+        o.params[:] = np.array([[p[0][0] for p in p0], [p[0][1] for p in p0], [p[1] for p in p0], [1.0 / p[2] for p in p0],
+                                [p[3] for p in p0], [p[4] for p in p0], [p[5] for p in p0], [p[6] for p in p0]], np.float32).reshape(8, 1, K)
+        std0 = o.params[1].copy()
+        for st in seq["steps"]:
+            ts = orc.TapeSource()
+            ts.set_volumes(np.zeros((1, K), np.int32))
+            ts.set_drift_uniforms(np.array(st["uniforms"]).reshape(3, 1, K))
+            out = o.step(np.full((1, K), 0.5, np.float32), 10.0, tape=ts)
+            assert out["impressions"].sum() == 0 and not o.drift_pending.any()
+            ref = st["params"]
+            np.testing.assert_allclose(o.params[0, 0], [p[0][0] for p in ref], rtol=2e-6, atol=2e-6)
+            assert np.array_equal(o.params[1], std0)
+            np.testing.assert_allclose(o.params[4, 0], [p[3] for p in ref], rtol=2e-6)
+            np.testing.assert_allclose(o.params[5, 0], [p[4] for p in ref], rtol=2e-6)
+            np.testing.assert_allclose(o.params[4, 0], st["kw_bctr"], rtol=2e-6)
+
+
 def test_g4_uniform_draws_are_the_env_generator(golden):
     """reset(seed) then update_keywords(): the three uniform vectors come from np_random in order vol, ctr, cvr."""
     s = golden("g4_update_keywords.json")["sequences"][0]
