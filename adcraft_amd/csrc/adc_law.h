@@ -1,7 +1,8 @@
 // adc_law.h - the engine's random stream and sampling law (gfx950 device code; the few scalar
 // FFI shims reuse it on the host).
 //
-// Stream: Philox4x32-10 (Salmon et al., SC11), counter-addressed, no per-lane state in HBM:
+// Stream (revision 2): Philox4x32-7 (Salmon et al., SC11; 7 rounds is the Crush-resistant variant of the paper's Table 2,
+// the 10-round default adds a safety margin), counter-addressed, no per-lane state in HBM:
 //     words = philox(key = env key (64 bit), ctr = (index, stage, keyword, tick))
 // so a variate depends only on WHAT it is for - never on which lane, wave, block or GPU drew it.
 // Transforms are float32 and use only operations that IEEE-754 rounds correctly
@@ -28,9 +29,10 @@
 
 namespace adc {
 
+// both:     call (0, ST_VOL, k/4)  = the volume words of keywords 4*(k/4) .. +3 (x,y,z,w for k%4 = 0..3)
 // IMPLICIT: call (j/4, ST_AUCTION) = one word per auction j (x,y,z,w for j%4 = 0..3); the word decides the
 //           click AND supplies the competitor-bid uniform (interval splitting, see AuctionLaw);
-//           call (j, ST_CONV)      = {conversion, revenue u1, revenue u2} words (x,y,z), consumed only for a paid click.
+//           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
 enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8, ST_AGENT = 9 };
@@ -61,10 +63,12 @@ ADC_HD void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
     c2 = n2;
 }
 
-ADC_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+constexpr int kPhiloxRounds = 7;
+
+ADC_HD U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < kPhiloxRounds; ++r) {
         philox_round(c0, c1, c2, c3, k0, k1);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -74,7 +78,15 @@ ADC_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 
 ADC_HD U4 draw(uint64_t key, uint32_t index, uint32_t stage, uint32_t keyword, uint32_t tick)
 {
-    return philox4x32_10(index, stage, keyword, tick, (uint32_t)key, (uint32_t)(key >> 32));
+    return philox4x32(index, stage, keyword, tick, (uint32_t)key, (uint32_t)(key >> 32));
+}
+
+// the volume word of keyword k: one call serves four consecutive keywords
+ADC_HD uint32_t volume_word(uint64_t key, uint32_t k, uint32_t tick)
+{
+    const U4 w = draw(key, 0u, 0u /* ST_VOL */, k >> 2, tick);
+    const uint32_t h = k & 3u;
+    return h == 0u ? w.x : h == 1u ? w.y : h == 2u ? w.z : w.w;
 }
 
 // ---- bit casts ---------------------------------------------------------------------------------
@@ -167,6 +179,53 @@ ADC_HD float normal_from_word(uint32_t w)
     return sign_bit(w) ? -val : val;
 }
 
+// ---- standard normal by table (revision 2) --------------------------------------------------------
+// One word -> N(0,1) by inversion: bit 31 = sign, bits 30..8 = m, t = 2m + 1 (odd, 24 bits), lower-tail probability
+// p = t / 2^25 in (0, 1/2).  |z| = -Phi^-1(p) is read from a table indexed by the FLOAT representation of t: 24 octaves x
+// 32 intervals (the float exponent and the top 5 mantissa bits), linear in the remaining 18 mantissa bits.  The nodes are
+// AS241 PPND7 values (the deterministic float32 code above), so host and device build the same bits; the chord error is
+// below 6e-5 in z everywhere (convex function: 32 intervals per octave), i.e. < 0.01 cent on a typical revenue.
+struct NormTableEntry { float value, slope; };
+constexpr int kNormTableEntries = 24 * 32;
+
+// -Phi^-1(p) >= 0 for p in (0, 1/2]: AS241 PPND7, central and intermediate branches (p >= 2^-25 keeps r below 5)
+ADC_HD float normal_tail_magnitude(float p)
+{
+    const float q = p - 0.5f;
+    if (q >= -0.425f) {
+        const float r = fma32(-q, q, 0.180625f);
+        const float num = fma32(fma32(fma32(5.9109374720e1f, r, 1.5929113202e2f), r, 5.0434271938e1f), r, 3.3871327179e0f);
+        const float den = fma32(fma32(fma32(6.7187563600e1f, r, 7.8757757664e1f), r, 1.7895169469e1f), r, 1.0f);
+        return -(q * num / den);
+    }
+    const float r = __builtin_sqrtf(-det_log(p)) - 1.6f;
+    const float num = fma32(fma32(fma32(1.7023821103e-1f, r, 1.3067284816e0f), r, 2.7568153900e0f), r, 1.4234372777e0f);
+    const float den = fma32(fma32(1.2021132975e-1f, r, 7.3700164250e-1f), r, 1.0f);
+    return num / den;
+}
+
+ADC_HD float norm_table_node(int i)            // |z| at the left end of interval i; node 768 is p = 1/2
+{
+    if (i >= kNormTableEntries) return 0.0f;
+    const float t0 = bits_to_float((uint32_t)(127 + (i >> 5)) << 23) * (1.0f + (float)(i & 31) * 0.03125f);     // 2^e (1 + m/32)
+    return normal_tail_magnitude(t0 * 2.98023223876953125e-08f);                                                  // p = t0 / 2^25
+}
+
+ADC_HD NormTableEntry norm_table_entry(int i)
+{
+    const float a = norm_table_node(i), b = norm_table_node(i + 1);
+    return NormTableEntry{a, (b - a) * 3.814697265625e-06f};            // slope per unit of the 18 low mantissa bits
+}
+
+ADC_HD float normal_tab(uint32_t w, const NormTableEntry *tab)
+{
+    const uint32_t t = ((w >> 7) & 0x00FFFFFEu) | 1u;                   // 2 * bits(30..8) + 1
+    const uint32_t bits = float_to_bits((float)t);                      // exact: t < 2^24
+    const NormTableEntry e = tab[(bits >> 18) - (127u << 5)];
+    const float z = fma32(e.slope, (float)(bits & 0x0003FFFFu), e.value);
+    return bits_to_float(float_to_bits(z) | (~w & 0x80000000u));        // sign bit set in the word: +|z|, clear: -|z|
+}
+
 ADC_HD int32_t money_to_cents(float dollars)
 {
     float c = __builtin_rintf(dollars * 100.0f);
@@ -221,46 +280,6 @@ ADC_HD float neg_log_u24(uint32_t w24, const LogTableEntry *tab)
     return -r;
 }
 
-// Standard normal from two words by Box-Muller: z = sqrt(-2 ln u1) * cos(2 pi u2).
-//   u1 = (odd 24-bit)/2^24 in (0,1) through the table log above; the angle is the top 24 bits of the second word:
-//   2 bits pick the quadrant, 22 bits (+1/2, so never on an axis) the position x in it; cos/sin of (pi/2) x are
-//   evaluated on (0, pi/4] after folding x -> 1 - x (Cephes single-precision minimax polynomials), then the quadrant
-//   decides which one and which sign.  No divisions, no data-dependent branches.
-ADC_HD float cos_2pi_from_word(uint32_t w)
-{
-    const uint32_t t = w >> 8;                                           // 24-bit phase
-    const uint32_t q = t >> 22;                                          // quadrant
-    const float x = ((float)(t & 0x003FFFFFu) + 0.5f) * 2.384185791015625e-07f;      // (0,1) within the quadrant
-    const bool fold = x > 0.5f;
-    const float a = (fold ? 1.0f - x : x) * 1.57079632679489661923f;     // (0, pi/4]
-    const float z = a * a;
-    float sp = fma32(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    sp = fma32(sp, z, -1.6666654611e-1f);
-    const float sn = fma32(sp * z, a, a);                                // sin(a)
-    float cp = fma32(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    cp = fma32(cp, z, 4.166664568298827e-2f);
-    const float cs = fma32(cp, z * z, fma32(-0.5f, z, 1.0f));            // cos(a)
-    // angle theta = (pi/2) x in the quadrant: (cos theta, sin theta) = fold ? (sn, cs) : (cs, sn)
-    const float c_th = fold ? sn : cs, s_th = fold ? cs : sn;
-    // cos(2 pi u) = cos(q pi/2 + theta):  q=0: cos  q=1: -sin  q=2: -cos  q=3: sin
-    const float v = (q & 1u) ? s_th : c_th;
-    return (q == 1u || q == 2u) ? -v : v;
-}
-
-ADC_HD float normal_box_muller(uint32_t w1, uint32_t w2, const LogTableEntry *tab)
-{
-    const float e = neg_log_u24((w1 >> 8) | 1u, tab);
-    return __builtin_sqrtf(e + e) * cos_2pi_from_word(w2);
-}
-
-// revenue of a conversion in cents, round2(max(N(mu, sd), 0.01)) (adcraft/synthetic_kw_helpers.py:66-70), IMPLICIT path
-ADC_HD int32_t revenue_cents_bm(uint32_t w1, uint32_t w2, float mu, float sd, const LogTableEntry *tab)
-{
-    float x = fma32(sd, normal_box_muller(w1, w2, tab), mu);
-    x = x > 0.01f ? x : 0.01f;
-    return money_to_cents(x);
-}
-
 // One word per auction.  click <=> word < T with T = round(ctr * 2^32) (as every Bernoulli here).  Inside
 // either outcome the word is still uniform on its sub-interval [0,T) or [T,2^32), so rescaling its offset d
 // to 24 bits, i24 = floor(d * 2^24 / range) computed as mulhi(d, floor(2^56 / range)), gives a uniform that is
@@ -301,15 +320,62 @@ ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 
-ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, const LogTableEntry *tab, bool &click)
+// The 24-bit uniform v of an auction, laid out so that the competitor's bid is MONOTONE in it (revision 2): bit 23 = sign
+// of the Laplace deviate z, bits 22..0 = magnitude index, reflected on the positive side:
+//     v < 2^23 :  z = -e(mag),  mag = v            (v up  =>  u up  =>  e = -log u down  =>  z up)
+//     v >= 2^23:  z = +e(mag),  mag = 2^24 - 1 - v (v up  =>  mag down  =>  e up  =>  z up)
+// with u = (2 mag + 1) / 2^24 and e(mag) = -log u by the table above.  X = loc + |scale| z and round(100 X) are then
+// non-decreasing in v (every step is a correctly rounded monotone operation), so {v : bid > cents(v)} is an interval - which
+// is what lets the step kernels resolve an auction by comparing its word with per-keyword thresholds.
+ADC_HD float laplace_deviate_from_v(uint32_t v24, const LogTableEntry *tab)
+{
+    const uint32_t neg_mask = 0u - (v24 >> 23);                                  // all ones on the positive side
+    const uint32_t mag = (v24 ^ neg_mask) & 0x007FFFFFu;
+    const float e = neg_log_u24((mag << 1) | 1u, tab);                          // e > 0
+    return bits_to_float(float_to_bits(e) ^ (~neg_mask & 0x80000000u));         // negative side: -e
+}
+
+// round(100 X) with its sign, clamped to +-1e9: non-decreasing in v.  |.| of it is the competitor's bid in cents.
+ADC_HD int32_t signed_cents_from_v(uint32_t v24, float loc, float scale, const LogTableEntry *tab)
+{
+    const float x = fma32(__builtin_fabsf(scale), laplace_deviate_from_v(v24, tab), loc);
+    float c = __builtin_rintf(x * 100.0f);
+    c = c < kMoneyMaxCents ? c : kMoneyMaxCents;          // (NaN -> +1e9: a NaN parameter never wins)
+    c = c > -kMoneyMaxCents ? c : -kMoneyMaxCents;
+    return (int32_t)c;
+}
+
+ADC_HD int32_t competitor_cents_from_v(uint32_t v24, float loc, float scale, const LogTableEntry *tab)
+{
+    const int32_t c = signed_cents_from_v(v24, loc, scale, tab);
+    return c < 0 ? -c : c;
+}
+
+// the 24-bit uniform of an auction word (click decided, offset rescaled inside its sub-interval)
+ADC_HD uint32_t auction_uniform24(uint32_t w, const AuctionLaw &a, bool &click)
 {
     click = bernoulli32(w, a.t32);
     const uint32_t d = click ? w : w - a.t32;
-    uint32_t i24 = mulhi32(d, click ? a.m_click : a.m_noclick);
-    i24 = i24 < 0x00FFFFFFu ? i24 : 0x00FFFFFFu;
-    const float r = -neg_log_u24(i24 | 1u, tab);                 // log u <= 0, u = (2*mag + 1) / 2^24 in (0,1), mag = i24 >> 1
-    const float z = bits_to_float(float_to_bits(r) ^ (i24 << 31));                  // bit 0 set: -log u, clear: +log u
-    return money_to_cents(__builtin_fabsf(fma32(scale, z, loc)));
+    const uint32_t v = mulhi32(d, click ? a.m_click : a.m_noclick);
+    return v < 0x00FFFFFFu ? v : 0x00FFFFFFu;
+}
+
+// 2nd-price clearing against one competitor: the bid must exceed the competitor's (a tie loses,
+// adcraft/synthetic_kw_helpers.py:167-170).  The single word 2^32 - 1 never wins (revision 2): it keeps every threshold of
+// the word-space form of this test (k_step_implicit_fast) within 32 bits, at a cost of 2^-32 in win probability.
+ADC_HD bool auction_wins(uint32_t w, int32_t bid_c, int32_t comp_c) { return bid_c > comp_c && w != 0xFFFFFFFFu; }
+
+ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, const LogTableEntry *tab, bool &click)
+{
+    return competitor_cents_from_v(auction_uniform24(w, a, click), loc, scale, tab);
+}
+
+// revenue of a conversion in cents, round2(max(N(mu, sd), 0.01)) (adcraft/synthetic_kw_helpers.py:66-70), IMPLICIT path
+ADC_HD int32_t revenue_cents_tab(uint32_t w, float mu, float sd, const NormTableEntry *tab)
+{
+    float x = fma32(sd, normal_tab(w, tab), mu);
+    x = x > 0.01f ? x : 0.01f;
+    return money_to_cents(x);
 }
 
 ADC_HD int32_t revenue_cents(uint32_t w, float mu, float sd)
@@ -319,9 +385,9 @@ ADC_HD int32_t revenue_cents(uint32_t w, float mu, float sd)
     return money_to_cents(x);
 }
 
-ADC_HD int32_t volume_from_word(uint32_t w, float mean, float sd)
+ADC_HD int32_t volume_from_word(uint32_t w, float mean, float sd, const NormTableEntry *tab)
 {
-    float x = fma32(sd, normal_from_word(w), mean);
+    float x = fma32(sd, normal_tab(w, tab), mean);
     x = x > 0.0f ? x : 0.0f;
     x = x < (float)kVolumeMax ? x : (float)kVolumeMax;
     const float t = __builtin_truncf(x);
@@ -414,10 +480,10 @@ ADC_HD void generate_implicit_keyword(uint64_t key, uint32_t kw, uint32_t serial
                                       float out[8])
 {
     const uint32_t c3 = 0xFFFF0000u | (serial & 0xFFFFu);
-    const U4 a = philox4x32_10(0u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
-    const U4 b = philox4x32_10(1u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
-    const U4 c = philox4x32_10(2u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
-    const U4 d = philox4x32_10(3u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 a = philox4x32(0u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 b = philox4x32(1u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 c = philox4x32(2u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const U4 d = philox4x32(3u, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
     const float v = quantile_sample(tab[0], a.x, a.y);
     const float r = unit_closed24(a.w);
     const bool has = unit_closed24(a.z) > no_vol_prob && v == v;          // :298-300 (NaN volume -> no volume)

@@ -47,7 +47,7 @@ ADC_EXPORT int64_t adc_count_true(const uint8_t *x, int64_t n)
 
 static inline adc::U4 shim_draw(uint64_t seed, uint64_t counter, uint32_t lane)
 {
-    return adc::philox4x32_10((uint32_t)counter, (uint32_t)(counter >> 32), lane, 0x5348494Du /* "SHIM" */,
+    return adc::philox4x32((uint32_t)counter, (uint32_t)(counter >> 32), lane, 0x5348494Du /* "SHIM" */,
                               (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 

@@ -22,7 +22,7 @@
  *            (competitor bids, click booleans, conversion booleans, revenues ...).  Pinned
  *            bit-exactly against tests/golden/g3_*.json and g8_*.json, which were recorded
  *            from the reference itself (tools/gen_golden.py).
- *   PHILOX - the production stream: Philox4x32-10 addressed by (env key; auction index, stage,
+ *   PHILOX - the production stream (revision 2): Philox4x32-7 addressed by (env key; auction index, stage,
  *            keyword, tick), with float32 transforms built only from IEEE-exact operations
  *            (+ - * / sqrt fma rint), so a GPU computes bit-identical values.  The Philox core is
  *            pinned by the Random123 known-answer vectors, the transforms by closed forms
@@ -49,18 +49,22 @@ enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1 };
 enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT };
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
 enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8 };
-/* IMPLICIT stream layout: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the
- * click (word < T) and, rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome);
- * call (j, ST_CONV) holds {conversion, revenue u1, revenue u2} words (x,y,z) of auction j, only consumed for a paid click. */
+/* Stream layout (revision 2): call (0, ST_VOL, k/4) holds the volume words of keywords 4(k/4)..+3 (word k%4).
+ * IMPLICIT: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the click (word < T) and,
+ * rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome); the word 2^32-1 never wins;
+ * call (j, ST_CONV) holds {conversion, revenue} words (x,y) of auction j, only consumed for a paid click. */
 #define ORC_TIMESTEPS 24
 #define ORC_VMAX (1 << 20)
 
-/* ------------------------------------------------------------------ Philox4x32-10 */
-/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC11); constants of Random123. */
-ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+/* ------------------------------------------------------------------ Philox4x32-R */
+/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC11); constants of Random123.  The stream uses R = 7
+ * (the paper's Crush-resistant round count; 10 is its default with a safety margin); both are pinned by the Random123
+ * known-answer vectors in tests/test_oracle_scalar.py. */
+#define ORC_PHILOX_ROUNDS 7
+ORC_API void orc_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -72,12 +76,16 @@ ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+ORC_API void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    orc_philox4x32_r(ctr, key, ORC_PHILOX_ROUNDS, out);
+}
 
 static void draw(uint64_t key, uint32_t index, uint32_t stage, uint32_t kw, uint32_t tick, uint32_t w[4])
 {
     uint32_t c[4] = { index, stage, kw, tick };
     uint32_t k[2] = { (uint32_t)key, (uint32_t)(key >> 32) };
-    orc_philox4x32_10(c, k, w);
+    orc_philox4x32(c, k, w);
 }
 
 /* ------------------------------------------------------------------ deterministic f32 math */
@@ -203,34 +211,51 @@ ORC_API float orc_neg_log_u24(uint32_t w24)
     return -r;
 }
 
-/* Box-Muller normal from two words: sqrt(-2 ln u1) cos(2 pi u2); u1 through the table log, the cosine by quadrant
- * folding to (0, pi/4] and Cephes single-precision sin/cos polynomials (no division, no libm) */
-ORC_API float orc_cos_2pi_from_word(uint32_t w)
+/* Standard normal from ONE word by a table of the inverse CDF (revision 2).  bit 31 = sign, bits 30..8 = m, t = 2m + 1,
+ * lower-tail probability p = t / 2^25 in (0, 1/2); |z| = -Phi^-1(p) is interpolated linearly inside one of 24 x 32
+ * intervals addressed by the float representation of t (exponent, top 5 mantissa bits).  Nodes: AS241 PPND7 (the code of
+ * orc_normal_from_word), so the table holds the same bits wherever it is built. */
+#define ORC_NORM_ENTRIES 768
+static float g_norm_value[ORC_NORM_ENTRIES + 1], g_norm_slope[ORC_NORM_ENTRIES];
+static int g_norm_ready = 0;
+static float tail_magnitude(float p)            /* -Phi^-1(p), 0 < p <= 1/2 */
 {
-    const uint32_t t = w >> 8, q = t >> 22;
-    const float x = ((float)(t & 0x003FFFFFu) + 0.5f) * 2.384185791015625e-07f;
-    const int fold = x > 0.5f;
-    const float a = (fold ? 1.0f - x : x) * 1.57079632679489661923f;
-    const float z = a * a;
-    float sp = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    sp = fmaf(sp, z, -1.6666654611e-1f);
-    const float sn = fmaf(sp * z, a, a);
-    float cp = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    cp = fmaf(cp, z, 4.166664568298827e-2f);
-    const float cs = fmaf(cp, z * z, fmaf(-0.5f, z, 1.0f));
-    const float c_th = fold ? sn : cs, s_th = fold ? cs : sn;
-    const float v = (q & 1u) ? s_th : c_th;
-    return (q == 1u || q == 2u) ? -v : v;
+    float q = p - 0.5f;
+    if (q >= -0.425f) {
+        float r = fmaf(-q, q, 0.180625f);
+        float num = fmaf(fmaf(fmaf(5.9109374720e1f, r, 1.5929113202e2f), r, 5.0434271938e1f), r, 3.3871327179e0f);
+        float den = fmaf(fmaf(fmaf(6.7187563600e1f, r, 7.8757757664e1f), r, 1.7895169469e1f), r, 1.0f);
+        return -(q * num / den);
+    } else {
+        float r = sqrtf(-orc_det_logf(p)) - 1.6f;
+        float num = fmaf(fmaf(fmaf(1.7023821103e-1f, r, 1.3067284816e0f), r, 2.7568153900e0f), r, 1.4234372777e0f);
+        float den = fmaf(fmaf(1.2021132975e-1f, r, 7.3700164250e-1f), r, 1.0f);
+        return num / den;
+    }
 }
-ORC_API float orc_normal_box_muller(uint32_t w1, uint32_t w2)
+static void build_norm_table(void)
 {
-    const float e = orc_neg_log_u24((w1 >> 8) | 1u);
-    return sqrtf(e + e) * orc_cos_2pi_from_word(w2);
+    for (int i = 0; i < ORC_NORM_ENTRIES; ++i) {
+        float t0 = ldexpf(1.0f + (float)(i & 31) * 0.03125f, i >> 5);      /* left end of interval i, in units of t */
+        g_norm_value[i] = tail_magnitude(t0 * 2.98023223876953125e-08f);   /* p = t0 / 2^25 */
+    }
+    g_norm_value[ORC_NORM_ENTRIES] = 0.0f;                                 /* p = 1/2 */
+    for (int i = 0; i < ORC_NORM_ENTRIES; ++i) g_norm_slope[i] = (g_norm_value[i + 1] - g_norm_value[i]) * 3.814697265625e-06f;
+    g_norm_ready = 1;
+}
+ORC_API float orc_normal_tab(uint32_t w)
+{
+    if (!g_norm_ready) build_norm_table();
+    const uint32_t t = 2u * ((w >> 8) & 0x007FFFFFu) + 1u;
+    const uint32_t bits = as_u32((float)t);
+    const uint32_t i = (bits >> 18) - (127u << 5);
+    const float z = fmaf(g_norm_slope[i], (float)(bits & 0x0003FFFFu), g_norm_value[i]);
+    return (w >> 31) ? z : -z;
 }
 /* IMPLICIT revenue in cents: round2(max(N(mu, sd), 0.01))  (synthetic_kw_helpers.py:66-70) */
-ORC_API int32_t orc_revenue_cents_bm(uint32_t w1, uint32_t w2, float mu, float sd)
+ORC_API int32_t orc_revenue_cents_tab(uint32_t w, float mu, float sd)
 {
-    float x = fmaf(sd, orc_normal_box_muller(w1, w2), mu);
+    float x = fmaf(sd, orc_normal_tab(w), mu);
     x = fmaxf(x, 0.01f);
     float c = rintf(x * 100.0f);
     if (!(c < 1.0e9f)) c = 1.0e9f;
@@ -244,21 +269,42 @@ static uint32_t rescale_multiplier(uint64_t range)      /* floor(2^56 / range) i
     if (!(m < 4294967040.0f)) m = 4294967040.0f;
     return (uint32_t)m;
 }
+/* competitor bid in cents from the auction's 24-bit uniform v.  Layout (revision 2): v < 2^23 is the negative side of the
+ * Laplace deviate, z = -e(v); v >= 2^23 the positive side, z = +e(2^24 - 1 - v); e(m) = -log((2m + 1) / 2^24) by the
+ * table.  loc + |scale| z is non-decreasing in v. */
+ORC_API int32_t orc_competitor_cents_from_v(uint32_t v, float loc, float scale)
+{
+    float z;
+    if (v < 0x00800000u) z = -orc_neg_log_u24(2u * v + 1u);
+    else z = orc_neg_log_u24(2u * (0x00FFFFFFu - v) + 1u);
+    const float a = fabsf(fmaf(fabsf(scale), z, loc));
+    float c = rintf(a * 100.0f);
+    if (!(c < 1.0e9f)) c = 1.0e9f;
+    return (int32_t)c;
+}
+/* checker: number of v in [1, 2^24) at which the Laplace deviate z(v) DEcreases (must be 0: the thresholds of
+ * k_step_implicit_fast rest on z, hence loc + |scale| z and its rounding to cents, being monotone in v) */
+ORC_API int64_t orc_check_deviate_monotone(void)
+{
+    int64_t bad = 0;
+    float prev = -orc_neg_log_u24(1u);
+    for (uint32_t v = 1; v < 0x01000000u; ++v) {
+        const float z = v < 0x00800000u ? -orc_neg_log_u24(2u * v + 1u) : orc_neg_log_u24(2u * (0x00FFFFFFu - v) + 1u);
+        if (!(z >= prev)) ++bad;
+        prev = z;
+    }
+    return bad;
+}
 ORC_API int32_t orc_auction_outcome(uint32_t w, float bctr, float loc, float scale, int32_t *click_out)
 {
     const uint64_t T = orc_bernoulli_threshold(bctr);
     const int click = (uint64_t)w < T;
     const uint32_t d = click ? w : w - (uint32_t)T;
     const uint32_t m = click ? rescale_multiplier(T) : rescale_multiplier(4294967296ull - T);
-    uint32_t i24 = (uint32_t)(((uint64_t)d * m) >> 32);     /* ~ floor(d * 2^24 / range): integer multiply */
-    if (i24 > 0x00FFFFFFu) i24 = 0x00FFFFFFu;
-    const float e = orc_neg_log_u24(i24 | 1u);                  /* u = (2*mag + 1) / 2^24 */
-    const float z = (i24 & 1u) ? e : -e;
-    const float a = fabsf(fmaf(scale, z, loc));
-    float c = rintf(a * 100.0f);
-    if (!(c < 1.0e9f)) c = 1.0e9f;
+    uint32_t v = (uint32_t)(((uint64_t)d * m) >> 32);     /* ~ floor(d * 2^24 / range): integer multiply */
+    if (v > 0x00FFFFFFu) v = 0x00FFFFFFu;
     *click_out = click;
-    return (int32_t)c;
+    return orc_competitor_cents_from_v(v, loc, scale);
 }
 
 /* revenue in cents: round2(max(N(mu, sd), 0.01))  (synthetic_kw_helpers.py:66-70) */
@@ -274,7 +320,7 @@ ORC_API int32_t orc_revenue_cents_from_word(uint32_t w, float mu, float sd)
 /* volume: round_half_away(max(N(mean, sd), 0))  (src/lib.rs:314-325) */
 ORC_API int32_t orc_volume_from_word(uint32_t w, float mean, float sd)
 {
-    float x = fmaf(sd, orc_normal_from_word(w), mean);
+    float x = fmaf(sd, orc_normal_tab(w), mean);
     x = fmaxf(x, 0.0f);
     if (!(x < (float)ORC_VMAX)) x = (float)ORC_VMAX;
     float t = truncf(x);
@@ -507,8 +553,8 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
         if (use_tape) V[k] = tape->volumes[base + k];
         else {
             uint32_t w[4];
-            draw(key, 0, ST_VOL, (uint32_t)k, tick, w);
-            V[k] = orc_volume_from_word(w[0], P(s, c, P_VOL_MEAN, env, k), P(s, c, P_VOL_STD, env, k));
+            draw(key, 0, ST_VOL, (uint32_t)k >> 2, tick, w);        /* one call serves four consecutive keywords */
+            V[k] = orc_volume_from_word(w[k & 3], P(s, c, P_VOL_MEAN, env, k), P(s, c, P_VOL_STD, env, k));
         }
         o->impressions[base + k] = o->clicks[base + k] = o->conversions[base + k] = 0;
         o->cost_cents[base + k] = o->revenue_cents[base + k] = 0;
@@ -548,13 +594,16 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                     int32_t click_bit = 0;
                     const uint32_t j = (uint32_t)(j0 + i);
                     int64_t comp;
+                    uint32_t word = 0;
                     if (use_tape) comp = tape->bid_cents[tape->cur_bid++];
                     else {
                         uint32_t w[4];
                         draw(key, j >> 2, ST_AUCTION, (uint32_t)k, tick, w);
-                        comp = orc_auction_outcome(w[j & 3u], P(s, c, P_BCTR, env, k), loc, scale, &click_bit);
+                        word = w[j & 3u];
+                        comp = orc_auction_outcome(word, P(s, c, P_BCTR, env, k), loc, scale, &click_bit);
                     }
                     if (!(bid_c > comp)) continue;             /* tie loses, helpers.py:167-170 */
+                    if (!use_tape && word == 0xFFFFFFFFu) continue;   /* stream rule: the word 2^32-1 never wins */
                     ++wins;
                     int clicked = use_tape ? tape->click[click_cur + wins - 1] : click_bit;
                     if (!clicked || broke) continue;
@@ -566,7 +615,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                         int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w2[0] < t_conv);
                         if (conv) {
                             int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
-                                                   : orc_revenue_cents_bm(w2[1], w2[2], rev_mu, rev_sd);
+                                                   : orc_revenue_cents_tab(w2[1], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
                         }
@@ -693,6 +742,7 @@ ORC_API int32_t orc_step(const orc_config *c, orc_state *s, const float *bids, c
     if (!c || !s || !bids || !budget || !o) return -1;
     if (c->num_envs <= 0 || c->num_keywords <= 0) return -1;
     if (!g_log_ready) build_log_table();
+    if (!g_norm_ready) build_norm_table();
     if (tape || c->threads <= 1) {
         for (int e = 0; e < c->num_envs; ++e)
             step_env(c, s, e, bids, budget[e], tape, o);
@@ -744,7 +794,7 @@ ORC_API void orc_generate_implicit_keywords(int32_t N, int32_t K, const uint64_t
             uint32_t w[4][4];
             for (uint32_t i = 0; i < 4; ++i) {
                 uint32_t c[4] = { i, ST_KEYGEN, (uint32_t)k, c3 }, kk[2] = { (uint32_t)key[e], (uint32_t)(key[e] >> 32) };
-                orc_philox4x32_10(c, kk, w[i]);
+                orc_philox4x32(c, kk, w[i]);
             }
             float out[8];
             const float v = quantile_sample(mins[0], meds[0], maxs[0], buckets[0], w[0][0], w[0][1]);

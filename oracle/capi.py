@@ -57,7 +57,8 @@ def lib():
         plain, fma = _build.build()
         _lib = C.CDLL(fma if _cpu_has_fma() else plain)
         L = _lib
-        L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_philox4x32_r.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_det_logf.restype = C.c_float
         L.orc_det_logf.argtypes = [C.c_float]
         L.orc_det_expf.restype = C.c_float
@@ -66,12 +67,14 @@ def lib():
         L.orc_normal_from_word.argtypes = [C.c_uint32]
         L.orc_laplace_cents_from_word.restype = C.c_int32
         L.orc_laplace_cents_from_word.argtypes = [C.c_uint32, C.c_float, C.c_float]
-        L.orc_cos_2pi_from_word.restype = C.c_float
-        L.orc_cos_2pi_from_word.argtypes = [C.c_uint32]
-        L.orc_normal_box_muller.restype = C.c_float
-        L.orc_normal_box_muller.argtypes = [C.c_uint32, C.c_uint32]
-        L.orc_revenue_cents_bm.restype = C.c_int32
-        L.orc_revenue_cents_bm.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+        L.orc_normal_tab.restype = C.c_float
+        L.orc_normal_tab.argtypes = [C.c_uint32]
+        L.orc_revenue_cents_tab.restype = C.c_int32
+        L.orc_revenue_cents_tab.argtypes = [C.c_uint32, C.c_float, C.c_float]
+        L.orc_check_deviate_monotone.restype = C.c_int64
+        L.orc_check_deviate_monotone.argtypes = []
+        L.orc_competitor_cents_from_v.restype = C.c_int32
+        L.orc_competitor_cents_from_v.argtypes = [C.c_uint32, C.c_float, C.c_float]
         L.orc_neg_log_u24.restype = C.c_float
         L.orc_neg_log_u24.argtypes = [C.c_uint32]
         L.orc_auction_outcome.restype = C.c_int32
@@ -109,11 +112,18 @@ def lib():
     return _lib
 
 
-def philox(ctr, key):
+PHILOX_ROUNDS = 7        # the stream's round count (oracle/adcraft_oracle.c ORC_PHILOX_ROUNDS)
+
+
+def philox(ctr, key, rounds=None):
+    """Philox4x32 with the stream's round count (or `rounds`)"""
     c = np.asarray(ctr, dtype=np.uint32)
     k = np.asarray(key, dtype=np.uint32)
     o = np.zeros(4, dtype=np.uint32)
-    lib().orc_philox4x32_10(c.ctypes.data, k.ctypes.data, o.ctypes.data)
+    if rounds is None:
+        lib().orc_philox4x32(c.ctypes.data, k.ctypes.data, o.ctypes.data)
+    else:
+        lib().orc_philox4x32_r(c.ctypes.data, k.ctypes.data, int(rounds), o.ctypes.data)
     return o
 
 

@@ -11,11 +11,11 @@ from oracle import ref_numpy as rn
 L = orc.lib()
 
 
-def _py_philox(ctr, key):
-    """independent pure-Python Philox4x32-10 (Salmon et al. SC11)"""
+def _py_philox(ctr, key, rounds=orc.PHILOX_ROUNDS):
+    """independent pure-Python Philox4x32-R (Salmon et al. SC11)"""
     c = list(ctr)
     k = list(key)
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = 0xD2511F53 * c[0]
         p1 = 0xCD9E8D57 * c[2]
         c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
@@ -23,19 +23,25 @@ def _py_philox(ctr, key):
     return c
 
 
-# Random123 kat_vectors, "philox4x32 10"
+# Random123 kat_vectors: "philox4x32 7" (the stream's round count since revision 2) and "philox4x32 10"
 KAT = [
-    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
-    ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
-    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+    (7, (0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+    (7, (0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+    (7, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)),
+    (10, (0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    (10, (0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    (10, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
      (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
 ]
 
 
-@pytest.mark.parametrize("ctr,key,exp", KAT)
-def test_philox_known_answers(ctr, key, exp):
-    assert tuple(int(x) for x in orc.philox(ctr, key)) == exp
-    assert tuple(_py_philox(ctr, key)) == exp
+@pytest.mark.parametrize("rounds,ctr,key,exp", KAT)
+def test_philox_known_answers(rounds, ctr, key, exp):
+    assert tuple(int(x) for x in orc.philox(ctr, key, rounds)) == exp
+    assert tuple(_py_philox(ctr, key, rounds)) == exp
+    if rounds == orc.PHILOX_ROUNDS:
+        assert tuple(int(x) for x in orc.philox(ctr, key)) == exp          # what the stream draws
 
 
 def test_philox_random_counters_match_python():
@@ -191,21 +197,43 @@ def test_auction_word_law_click_and_bid_are_independent_and_right():
     assert L.orc_auction_outcome(4294967295, 1.0, float(loc), float(scale), C.byref(click)) >= 0 and click.value == 1
 
 
-def test_box_muller_normal_and_cosine():
-    """IMPLICIT revenue normal: cos(2 pi u) against numpy over the whole phase range, and the N(0,1) law"""
-    ws = np.concatenate([np.arange(0, 2**32, 2**19, dtype=np.uint64) + np.uint64(12345), _words(20000, 31)])
-    got = np.array([L.orc_cos_2pi_from_word(int(w)) for w in ws], dtype=np.float64)
-    t = (ws >> np.uint64(8)).astype(np.float64)
-    phase = ((t // 2**22) + ((t % 2**22) + 0.5) / 2**22) / 4.0
-    assert np.abs(got - np.cos(2 * np.pi * phase)).max() < 3e-7
+def test_table_normal_is_the_inverse_cdf_and_the_revenue_law():
+    """orc_normal_tab: N(0,1) by a 24 x 32-interval table of the inverse CDF (nodes AS241 PPND7, linear inside): absolute
+    error below 6e-5 everywhere against scipy, antisymmetric in the sign bit, monotone in the word; and the revenue law
+    built on it against the reference's rev_normal (synthetic_kw_helpers.py:66-70)."""
+    ws = np.concatenate([np.arange(0, 2**31, 2**17, dtype=np.uint64) + np.uint64(0x80), _words(50000, 31) >> np.uint64(1),
+                         np.arange(0, 2**12, dtype=np.uint64) << np.uint64(8), np.uint64(2**31 - 1) - (np.arange(0, 2**12, dtype=np.uint64) << np.uint64(8))])
+    neg = np.array([L.orc_normal_tab(int(w)) for w in ws], dtype=np.float64)                       # sign bit clear: lower tail
+    pos = np.array([L.orc_normal_tab(int(w) | 0x80000000) for w in ws], dtype=np.float64)
+    assert np.array_equal(pos, -neg) and (neg <= 0).all()
+    p = (2.0 * ((ws >> np.uint64(8)) & np.uint64(0x7FFFFF)).astype(np.float64) + 1.0) * 2.0 ** -25
+    assert np.abs(neg - stats.norm.ppf(p)).max() < 6e-5
+    order = np.argsort(ws, kind="stable")
+    assert (np.diff(neg[order]) >= 0).all()                                                             # monotone in the word
+    assert L.orc_normal_tab(0) < -5.3 and L.orc_normal_tab(0x80000000) > 5.3
     n = 300_000
-    w1, w2 = _words(n, 32), _words(n, 33)
-    z = np.array([L.orc_normal_box_muller(int(a), int(b)) for a, b in zip(w1, w2)], dtype=np.float64)
+    z = np.array([L.orc_normal_tab(int(w)) for w in _words(n, 32)], dtype=np.float64)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     assert stats.kstest(z, "norm").pvalue > 1e-4
-    mine = np.array([L.orc_revenue_cents_bm(int(a), int(b), 1.0, 0.15) for a, b in zip(w1[:200000], w2[:200000])])
+    mine = np.array([L.orc_revenue_cents_tab(int(w), 1.0, 0.15) for w in _words(200000, 33)])
     ref = np.rint(rn.rev_normal(1.0, 0.15, np.random.default_rng(34))(200000) * 100).astype(int)
     assert stats.ks_2samp(mine, ref).pvalue > 1e-4 and mine.min() >= 1
+    low = np.array([L.orc_revenue_cents_tab(int(w), 0.0, 0.001) for w in _words(1000, 9)])
+    assert (low == 1).all()                                                                             # max(., 0.01) reproduced
+
+
+def test_competitor_bid_is_monotone_in_the_auction_uniform():
+    """revision 2 lays the 24-bit auction uniform out so that loc + |scale| z(v), hence the competitor's bid on either side
+    of zero, is monotone in v: the property the word-space thresholds of k_step_implicit_fast rest on.  Exhaustive over
+    every v for the deviate itself (it does not depend on the keyword), sampled for the cents."""
+    assert L.orc_check_deviate_monotone() == 0          # z(v) non-decreasing over all 2^24 values of v
+    rng = np.random.default_rng(4)
+    for _ in range(40):
+        loc, scale = float(np.float32(rng.uniform(0.05, 1.5))), float(np.float32(rng.uniform(0.003, 0.5)))
+        vs = np.sort(rng.integers(0, 1 << 24, 3000))
+        c = np.array([L.orc_competitor_cents_from_v(int(x), loc, scale) for x in vs])
+        turn = int(np.argmin(c))
+        assert (np.diff(c[:turn + 1]) <= 0).all() and (np.diff(c[turn:]) >= 0).all()        # V-shaped: |X| with X monotone
 
 
 def test_cents_to_dollars_is_the_ieee_quotient():
