@@ -125,6 +125,7 @@ def lib():
         "adc_nonneg_int_normal": ([f64, f64, u64, u64], u64),
         "adc_binomial": ([u64, f64, u64, u64], u64),
         "adc_cost_create": ([f64, i64, u64, u64, vp], C.c_int),
+        "adc_auction_word_intervals": ([f32, f32, f32, f32, vp], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)      # AttributeError here = the .so does not export what the header declares

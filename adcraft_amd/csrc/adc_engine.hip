@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

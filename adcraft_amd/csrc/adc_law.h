@@ -370,6 +370,87 @@ ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float
     return competitor_cents_from_v(auction_uniform24(w, a, click), loc, scale, tab);
 }
 
+// ---- the auction resolved in word space --------------------------------------------------------------------------
+// signed_cents_from_v is non-decreasing in v, so "the bid exceeds the competitor's" is v in [W_lo, W_hi) with
+//     W_lo = min{v : S(v) >= -(bid-1)},   W_hi = min{v : S(v) >= bid}          (S = signed cents; cents = |S|)
+// and, since v = min(mulhi(d, m), 2^24 - 1) is non-decreasing in the word's offset d inside its click / no-click
+// sub-interval, it is d in [D(W_lo), D(W_hi)) with D(W) = min{d : v(d) >= W} = ceil(W 2^32 / m).  Per keyword that is two
+// word intervals - clicked wins and unclicked wins - and an auction costs two subtract-and-compare pairs instead of a
+// logarithm; the competitor's bid itself is only evaluated for the clicked wins, which pay it.  These functions find the
+// intervals EXACTLY (the oracle resolves every auction the long way; parity is bit for bit).
+
+// min{v in [0, 2^24] : signed_cents_from_v(v) >= target}.  A float estimate of the answer, a window around it that is
+// verified at both ends, bisection inside; if the estimate was off (degenerate parameters) the bisection runs over the
+// whole range instead - the result never depends on the estimate.
+ADC_HD uint32_t lower_bound_v(int32_t target, float loc, float scale, const LogTableEntry *tab)
+{
+    const float s = __builtin_fabsf(scale);
+    const float x_t = ((float)target - 0.5f) * 0.01f;                    // 100 x rounds to >= target from about here
+    const float z_t = (x_t - loc) / s;
+    const float e_t = __builtin_fabsf(z_t);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float mag_f = __builtin_amdgcn_exp2f(fma32(e_t, -1.44269504f, 23.0f));   // u 2^23, u = exp(-e)
+#else
+    float mag_f = exp2f(fma32(e_t, -1.44269504f, 23.0f));
+#endif
+    mag_f = mag_f < 8388607.0f ? mag_f : 8388607.0f;                     // (NaN -> the bound; any estimate will do)
+    mag_f = mag_f > 0.0f ? mag_f : 0.0f;
+    const uint32_t mag = (uint32_t)mag_f;
+    const uint32_t est = z_t < 0.0f ? mag : 0x00FFFFFFu - mag;
+    // how far the estimate can be off: the table log differs from log by < 4e-6 (x mag), exp2 and its argument by ~1e-6,
+    // and one ulp of x = loc + s z moves z by ulp / s
+    float slack = mag_f * (6.0e-6f + 2.4e-7f * (__builtin_fabsf(x_t) + __builtin_fabsf(loc)) / s);
+    slack = slack < 4194304.0f ? slack : 4194304.0f;                     // (NaN -> the bound)
+    const uint32_t half = 8u + (uint32_t)slack;
+    uint32_t lo = est > half ? est - half : 0u;
+    uint32_t hi = est + half < 0x01000000u ? est + half : 0x01000000u;
+    // wanted: S(lo - 1) < target (or lo == 0) and S(hi) >= target (or hi == 2^24)
+    if (lo > 0u && !(signed_cents_from_v(lo - 1u, loc, scale, tab) < target)) lo = 0u;
+    if (hi < 0x01000000u && !(signed_cents_from_v(hi, loc, scale, tab) >= target)) hi = 0x01000000u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (signed_cents_from_v(mid, loc, scale, tab) >= target) hi = mid;
+        else lo = mid + 1u;
+    }
+    return lo;
+}
+
+// min{d in [0, range] : min(mulhi(d, m), 2^24 - 1) >= W} for W in [0, 2^24]; `range` (<= 2^32) if no offset reaches W.
+ADC_HD uint64_t offset_reaching(uint32_t W, uint32_t m, uint64_t range)
+{
+    if (W == 0u) return 0ull;
+    if (W > 0x00FFFFFFu || m == 0u) return range;
+    const double q = ((double)W * 4294967296.0) / (double)m;             // W 2^32 / m, correctly rounded: within 2^-21 of it
+    if (!(q < (double)range)) return range;
+    uint64_t d = (uint64_t)q;                                            // floor or ceiling of the quotient
+    const uint64_t need = (uint64_t)W << 32;
+    if (d * m >= need) { if (d > 0ull && (d - 1ull) * m >= need) d -= 1ull; }
+    else { d += 1ull; if (d * m < need) d += 1ull; }
+    return d < range ? d : range;
+}
+
+// the two word intervals of a keyword: an auction word w is a clicked win iff (w - c_lo) < c_w, an unclicked win iff
+// (w - n_lo) < n_w (unsigned 32-bit arithmetic; widths fit because the word 2^32 - 1 never wins)
+struct WinIntervals { uint32_t c_lo, c_w, n_lo, n_w; };
+
+ADC_HD WinIntervals win_intervals(int32_t bid_c, float loc, float scale, uint64_t t_click, const AuctionLaw &law, const LogTableEntry *tab)
+{
+    const uint32_t w_lo = lower_bound_v(1 - bid_c, loc, scale, tab);     // bid > |cents|  <=>  -(bid - 1) <= S <= bid - 1
+    const uint32_t w_hi = lower_bound_v(bid_c, loc, scale, tab);
+    WinIntervals r{0u, 0u, 0u, 0u};
+    if (!(w_lo < w_hi)) return r;
+    const uint64_t top = 0xFFFFFFFFull;                                  // words at or above it never win
+    uint64_t a = offset_reaching(w_lo, law.m_click, t_click), b = offset_reaching(w_hi, law.m_click, t_click);
+    b = b < top ? b : top;
+    if (a < b) { r.c_lo = (uint32_t)a; r.c_w = (uint32_t)(b - a); }
+    const uint64_t range_n = 4294967296ull - t_click;
+    a = t_click + offset_reaching(w_lo, law.m_noclick, range_n);
+    b = t_click + offset_reaching(w_hi, law.m_noclick, range_n);
+    b = b < top ? b : top;
+    if (a < b) { r.n_lo = (uint32_t)a; r.n_w = (uint32_t)(b - a); }
+    return r;
+}
+
 // revenue of a conversion in cents, round2(max(N(mu, sd), 0.01)) (adcraft/synthetic_kw_helpers.py:66-70), IMPLICIT path
 ADC_HD int32_t revenue_cents_tab(uint32_t w, float mu, float sd, const NormTableEntry *tab)
 {

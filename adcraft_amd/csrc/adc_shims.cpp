@@ -84,3 +84,24 @@ ADC_EXPORT int adc_cost_create(double x, int64_t n, uint64_t seed, uint64_t coun
     }
     return ADC_OK;
 }
+
+// The word-space form of the 2nd-price clearing used by k_step_implicit_fast, evaluated on the host (same code,
+// adc_law.h): for a keyword (bid, competitor law, click rate) the auction word w is a clicked win iff
+// (w - out[0]) < out[1] and an unclicked win iff (w - out[2]) < out[3] in unsigned 32-bit arithmetic.  Diagnostic entry
+// point: lets a caller (and tests/test_abi_and_host.py) check the thresholds against auction-by-auction resolution
+// (adcraft/synthetic_kw_helpers.py:116-180 on the sampled competitor bid) without a GPU.
+ADC_EXPORT int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out4)
+{
+    if (!out4) return ADC_EINVAL;
+    static adc::LogTableEntry table[adc::kLogTableIntervals];
+    static bool ready = false;
+    if (!ready) {
+        for (int i = 0; i < adc::kLogTableIntervals; ++i) table[i] = adc::log_table_entry(i);
+        ready = true;
+    }
+    const adc::AuctionLaw law = adc::make_auction_law(buyside_ctr);
+    const adc::WinIntervals r = adc::win_intervals((int32_t)adc::bid_to_cents(bid), cost_loc, cost_scale,
+                                                   adc::bernoulli_threshold(buyside_ctr), law, table);
+    out4[0] = r.c_lo; out4[1] = r.c_w; out4[2] = r.n_lo; out4[3] = r.n_w;
+    return ADC_OK;
+}

@@ -317,6 +317,11 @@ int64_t adc_count_true(const uint8_t *x, int64_t n);                            
 uint64_t adc_nonneg_int_normal(double mean, double std, uint64_t seed, uint64_t counter);   /* :314-325 */
 uint64_t adc_binomial(uint64_t n, double p, uint64_t seed, uint64_t counter);               /* :70-76 */
 int adc_cost_create(double x, int64_t n, uint64_t seed, uint64_t counter, double *out_n);   /* :54-67 */
+/* diagnostic: the word-space thresholds k_step_implicit_fast resolves a keyword's auctions with (adc_law.h
+ * win_intervals): word w is a clicked win iff (w - out4[0]) < out4[1], an unclicked win iff (w - out4[2]) < out4[3]
+ * (uint32 arithmetic) - equivalent, word for word, to sampling the competitor's bid and running the reference's
+ * nth_price_auction env path on it (adcraft/synthetic_kw_helpers.py:116-180: win iff bid > competitor) */
+int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out4);
 
 #ifdef __cplusplus
 }

@@ -246,3 +246,49 @@ def test_header_is_plain_c_and_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", inc, os.path.join(ROOT, "examples", "c_abi_minimal.c"),
                            "-L", libdir, "-ladcraft_hip", "-Wl,-rpath," + libdir, "-o", exe])
     assert os.path.exists(exe)
+
+
+def test_word_space_intervals_equal_auction_by_auction_resolution():
+    """adc_law.h win_intervals (the product's threshold form of the 2nd-price clearing, run here on the host) against the
+    oracle resolving the same words one auction at a time: sample the competitor's bid from the word, win iff bid > bid of
+    the competitor (tie loses), the word 2^32 - 1 never wins.  Checked on the interval edges (every word where the outcome
+    can change), the ends of the click / no-click sub-intervals, and random words - for the BASELINE keyword laws and for
+    degenerate parameters."""
+    import ctypes as C
+    from oracle import capi as orc
+    L, O = _ffi.lib(), orc.lib()
+    rng = np.random.default_rng(12)
+    cases = []
+    for _ in range(60):
+        loc = rng.uniform(0.3, 1.0)
+        cases.append((round(rng.uniform(0.05, 1.6), 2), loc, max(0.01, rng.uniform(0.01, 0.3) * loc), rng.uniform(0.05, 0.95)))
+    cases += [(0.01, 0.55, 0.08, 0.5), (0.02, 0.001, 0.004, 0.5), (5.0, 0.55, 0.08, 0.5), (1e7, 0.55, 0.08, 0.5), (0.7, 0.55, 0.08, 0.0),
+              (0.7, 0.55, 0.08, 1.0), (0.7, 0.55, 0.0, 0.3), (0.7, 0.55, 1e-5, 0.3), (0.7, 0.55, 50.0, 0.3), (0.7, -0.4, 0.2, 0.3),
+              (0.7, 0.55, -0.08, 0.3), (0.7, float("nan"), 0.08, 0.3), (0.7, 0.55, float("nan"), 0.3), (0.7, 0.55, float("inf"), 0.3),
+              (0.7, 0.55, 0.08, 1e-9), (0.7, 0.55, 0.08, 1.0 - 1e-7), (0.64, 0.64, 0.05, 0.3), (0.3, 3.0, 0.2, 0.6)]
+    out = (C.c_uint32 * 4)()
+    click = C.c_int32()
+    n_edges = 0
+    for bid, loc, scale, ctr in cases:
+        bid, loc, scale, ctr = (float(np.float32(x)) for x in (bid, loc, scale, ctr))
+        assert L.adc_auction_word_intervals(bid, loc, scale, ctr, out) == 0
+        c_lo, c_w, n_lo, n_w = (int(x) for x in out)
+        bid_c = int(O.orc_bid_cents(bid))
+        T = int(O.orc_bernoulli_threshold(ctr))
+        words = {0, 1, 2**32 - 1, 2**32 - 2, max(T - 1, 0), min(T, 2**32 - 1), min(T + 1, 2**32 - 1)}
+        for lo, w in ((c_lo, c_w), (n_lo, n_w)):
+            for e in (lo - 1, lo, lo + 1, lo + w - 1, lo + w, lo + w + 1):
+                if 0 <= e < 2**32:
+                    words.add(e)
+        n_edges += len(words)
+        words |= set(int(x) for x in rng.integers(0, 2**32, 400, dtype=np.uint64))
+        for w in words:
+            comp = O.orc_auction_outcome(w, ctr, loc, scale, C.byref(click))
+            win = bid_c > comp and w != 2**32 - 1
+            cw = ((w - c_lo) & 0xFFFFFFFF) < c_w
+            nw = ((w - n_lo) & 0xFFFFFFFF) < n_w
+            assert not (cw and nw)
+            assert (cw or nw) == win, (bid, loc, scale, ctr, w, comp)
+            if win:
+                assert cw == bool(click.value)
+    assert n_edges > 500
