@@ -195,6 +195,39 @@ def test_run_days_graph_replay_equals_single_steps(amd, model):
         assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
 
 
+def test_day_graph_is_recaptured_when_settings_change(amd):
+    """The kernel nodes of a captured day hold the engine's settings by value.  Changing any of them between two
+    run_days(graph=True) calls - metrics on/off, episode limits, drift, flat observations, the bid-curve grid (which
+    re-allocates device memory the old graph would still point at) - must give what the un-captured loop gives."""
+    N, K = 5, 40
+    planes = H.implicit_params(N, K, seed=96, mean_volume=24, cvr=0.5)
+    outs = []
+    for graph in (True, False):
+        e = amd.StepEngine(N, K, seed=32, max_days=1 << 20, loss_threshold=1e12, auto_reset=True)
+        e.set_all_params(planes)
+        e.reset()
+        e.bid_curves_build(512, np.arange(0.01, 3.00, 0.01))
+        e.metrics_enable(False)
+        e.run_days("oracle", 6, budget=1e6, graph=graph)
+        e.metrics_enable(True)                              # was off when the graph was captured
+        e.metrics_reset()
+        e.run_days("oracle", 6, budget=1e6, graph=graph)
+        e.bid_curves_build(256, np.arange(0.05, 2.00, 0.05))   # another grid size: the curve buffers are re-allocated
+        e.run_days("oracle", 6, budget=1e6, graph=graph)
+        e.set_limits(4, 1e12)                               # episodes now end (auto-reset) every 4 days
+        e.set_drift(True, (0.05, 0.05, 0.05))
+        e.run_days("oracle", 9, budget=1e6, graph=graph)
+        o = e.fetch()
+        prof, ideal, ideal_pos = e.metrics_read_nk(ideal=True)
+        outs.append((o, e.get_all_params(), prof, ideal, e.metrics_read()[1]))
+        e.close()
+    a, b = outs
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert a[4][1] == 21 * N and a[4][2] > 0                # metric mode counted the 21 days after it was switched on; episodes ended
+
+
 def test_heatmap_cells_match_the_reference_end_to_end(amd, golden):
     """G11: cells of the paper's heat-map experiment run by the reference itself (its env, its agent, its metrics, the
     notebook's loop).  The device-resident loop on the same keyword sets (reset(seed) generation is bit-exact) must give
