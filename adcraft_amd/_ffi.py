@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ADC_OK, ADC_EINVAL, ADC_EHIP, ADC_ENOMEM, ADC_ESTATE, ADC_ETYPE = 0, -1, -2, -3, -4, -5
+ADC_OK, ADC_EINVAL, ADC_EHIP, ADC_ENOMEM, ADC_ESTATE, ADC_ETYPE, ADC_ERCCL = 0, -1, -2, -3, -4, -5, -6
 MODEL_IMPLICIT, MODEL_EXPLICIT = 0, 1
 P_VOL_MEAN, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT = range(9)
 (BUF_PARAMS, BUF_BIDS, BUF_BUDGET, BUF_IMPRESSIONS, BUF_CLICKS, BUF_CONVERSIONS, BUF_COST, BUF_REVENUE, BUF_REWARD,
@@ -63,6 +63,12 @@ def lib():
         except Exception as exc:  # no hipcc / compile error: there is nothing to fall back to
             if not os.path.exists(path):
                 raise EngineError(f"HIP engine library {path} is missing and could not be built: {exc}") from exc
+            # an older build exists but the sources have changed since: running it would silently test stale kernels
+            if os.environ.get("ADCRAFT_ALLOW_STALE_LIB") != "1":
+                raise EngineError(f"HIP engine library {path} is older than its sources and the rebuild failed: {exc} "
+                                  "(set ADCRAFT_ALLOW_STALE_LIB=1 to load the stale library anyway)") from exc
+            import warnings
+            warnings.warn(f"loading a STALE {path}: its sources changed and the rebuild failed ({exc})", RuntimeWarning)
     L = C.CDLL(path)
     L.adc_last_error.restype = C.c_char_p
     vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -126,6 +132,12 @@ def lib():
         "adc_binomial": ([u64, f64, u64, u64], u64),
         "adc_cost_create": ([f64, i64, u64, u64, vp], C.c_int),
         "adc_auction_word_intervals": ([f32, f32, f32, f32, vp], C.c_int),
+        "adc_comm_get_unique_id": ([vp], C.c_int),
+        "adc_engine_comm_init": ([vp, vp, i32, i32], C.c_int),
+        "adc_engine_comm_destroy": ([vp], C.c_int),
+        "adc_engine_comm_info": ([vp, vp, vp], C.c_int),
+        "adc_engine_metrics_allreduce": ([vp, vp, vp, vp], C.c_int),
+        "adc_engine_comm_allreduce_f64": ([vp, vp, i32, i32], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)      # AttributeError here = the .so does not export what the header declares

@@ -37,14 +37,31 @@ def stale():
 
 
 def build(force=False, verbose=False, extra=()):
+    """Compile if the library is missing or older than a source.  Safe under several processes at once (one rank per GPU
+    all import the package): the compile runs under an exclusive file lock into a temporary file that is renamed over
+    the library, so a concurrent dlopen sees the old library or the new one, never a partial file."""
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
     if not force and not stale():
         return LIB
-    srcs = [os.path.join(SRC_DIR, s) for s in SOURCES if os.path.exists(os.path.join(SRC_DIR, s))]
-    cmd = [HIPCC] + FLAGS + list(extra) + srcs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():          # another process built it while this one waited
+                return LIB
+            srcs = [os.path.join(SRC_DIR, s) for s in SOURCES if os.path.exists(os.path.join(SRC_DIR, s))]
+            tmp = f"{LIB}.tmp{os.getpid()}"
+            cmd = [HIPCC] + FLAGS + list(extra) + srcs + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

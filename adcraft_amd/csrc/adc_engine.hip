@@ -57,3 +57,4 @@ namespace adck {
 using namespace adck;
 
 #include "parts/host_api.inc"
+#include "parts/comm_api.inc"

@@ -314,6 +314,40 @@ class StepEngine:
 
     POLICIES = {"fixed": 0, "zero_margin": 1, "oracle": 2}
 
+    # ---- multi-GPU: the episode-metric all-reduce (RCCL behind the C ABI; adcraft_amd/comm.py brings it up) ----------
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        check(self._lib.adc_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world_size):
+        uid = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        check(self._lib.adc_engine_comm_init(self._h, uid, int(rank), int(world_size)))
+
+    def comm_destroy(self):
+        check(self._lib.adc_engine_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w = C.c_int32(0), C.c_int32(1)
+        check(self._lib.adc_engine_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def metrics_allreduce(self, ideal_k=None, ideal_pos_k=None):
+        """the one collective of the path: (profit_cents[K], ideal[K], ideal_pos[K], scalars[8]) summed over steps, envs and
+        the ranks of the engine's communicator (this rank alone without one)"""
+        K = self.num_keywords
+        out = np.zeros(3 * K + 8, dtype=np.float64)
+        a = None if ideal_k is None else np.ascontiguousarray(ideal_k, dtype=np.float64)
+        b = None if ideal_pos_k is None else np.ascontiguousarray(ideal_pos_k, dtype=np.float64)
+        check(self._lib.adc_engine_metrics_allreduce(self._h, None if a is None else a.ctypes.data,
+                                                     None if b is None else b.ctypes.data, out.ctypes.data))
+        return out[:K], out[K:2 * K], out[2 * K:3 * K], out[3 * K:]
+
+    def comm_allreduce(self, values, op="sum"):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(self._lib.adc_engine_comm_allreduce_f64(self._h, v.ctypes.data, v.size, 1 if op == "max" else 0))
+        return v
+
     def run_days(self, policy, days, budget=100000.0, graph=None):
         """`days` days of the device-resident loop in one call; graph=True replays pairs of days from a captured
         hipGraph (same results, measured no faster: tools/measure_small_loop.py)"""

@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the BiddingSimulation step engine on N MI355X GPUs of one node.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run, one rank per GPU.  A "step" is one pass of the hot path (one
-BiddingSimulation.step for every resident env) over device-resident synthetic actions.
-Workload at every N: BASELINE.json configs[1] per GPU (4096 envs x 256 keywords, dense stationary
-keyword law) - envs shard with no data-path collective, so scaling is weak; for N>1 the episode
-metric vector is all-reduced over RCCL (torch.distributed "nccl") every max_days steps.
-Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; rank 0 prints ONE JSON line.
+  * launched by `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) this process is one
+    rank; otherwise, with --gpus N > 1, it starts N fresh rank processes itself - before anything touches a GPU - collects
+    rank 0's line and fails if any rank fails.  No PyTorch anywhere: the one collective (the episode-metric all-reduce) is
+    the engine's own RCCL call behind the C ABI (adc_engine_metrics_allreduce), brought up by adcraft_amd/comm.py.
+  * A "step" is one pass of the hot path (one BiddingSimulation.step for every resident env) over device-resident
+    synthetic actions.
+  * Workload.  N = 1: BASELINE.json configs[1] (cfg2: 4096 envs x 256 keywords, dense stationary law) is `value`; the
+    largest single-GPU config (cfg3: 16384 x 1024, sparse volume) and the per-GPU shards of the 8-GPU configs are measured in
+    the same run and reported under "also".  N > 1: every GPU holds the BASELINE configs[3] shard (cfg4: 65536 x 1024 over
+    8 GPUs = 8192 x 1024 per GPU), envs shard with no data-path collective ("weak" scaling), the metric vector is
+    all-reduced once per 60-step episode inside the timed region; configs[4] (cfg5: drift) is under "also".
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,32 +28,246 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 instruction per 2 cycles per SIMD
 BYTES_PER_U = {False: 56, True: 68}   # 36 B read + 20 B written per keyword-step (+12 B drift write-back)
 BYTES_PER_ENV = 26
+MAX_DAYS = 60
+KERNEL_NAMES = ("k_step_implicit_fast", "k_tail_or_flag + k_step_exact_rows (step tail)", "k_metric_accumulate")
+# the reference's own Python loop, unmodified, on this keyword law: measured in the BUILD container (tools/time_reference_python.py,
+# one Xeon core @ 2.1 GHz, stand-ins for the two modules that cannot be imported there) - never on the GPU box, where
+# the reference does not exist
+REFERENCE_PYTHON = {"value": 631.0, "unit": "keyword-steps/s", "cores": 1,
+                    "provenance": "tools/time_reference_python.py in the build container (158 ms per 100-keyword env-day); DESIGN.md section 6"}
 
 
-def cpu_baseline(cfg_name, planes, K, seconds=12.0):
-    """the CPU oracle (a C restatement of the reference's loops, oracle/adcraft_oracle.c) on this host's cores,
-    on a bounded sample of the same workload"""
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(cfg_name, planes, K, seconds):
+    """the CPU oracle (a C restatement of the reference's loops, oracle/adcraft_oracle.c) on this host, on a bounded sample
+    of the same workload: one thread, then all cores"""
     from oracle import capi as orc
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-    n_envs = 8 * cores
-    o = orc.OracleEngine(n_envs, K, threads=cores)
-    o.params[:] = planes[:, :n_envs]
-    o.key[:] = np.arange(1, n_envs + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-    bids = o.sample_bids(0.3, 1.0)
-    o.step(bids, 1.0e9)                      # warm
+
+    def timed(threads, n_envs, budget_s):
+        o = orc.OracleEngine(n_envs, K, threads=threads)
+        o.params[:] = planes[:, :n_envs]
+        o.key[:] = np.arange(1, n_envs + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        bids = o.sample_bids(0.3, 1.0)
+        o.step(bids, 1.0e9)                      # warm
+        t0 = time.perf_counter()
+        steps = auctions = 0
+        while time.perf_counter() - t0 < budget_s:
+            out = o.step(bids, 1.0e9)
+            auctions += int(out["volumes"].sum())
+            steps += 1
+        dt = time.perf_counter() - t0
+        return n_envs * K * steps / dt, auctions / dt, steps, dt
+
+    one, one_a, s1, d1 = timed(1, 8, seconds * 0.4)
+    allc, all_a, s2, d2 = timed(cores, 8 * cores, seconds * 0.6)
+    return {"value": allc, "unit": "keyword-steps/s", "cores": cores, "kind": "port", "auctions_per_s": all_a,
+            "single_thread": {"value": one, "cores": 1, "auctions_per_s": one_a,
+                              "sample": f"8 envs x {K} keywords of {cfg_name}, {s1} steps, {d1:.1f} s"},
+            "sample": f"{8 * cores} envs x {K} keywords of {cfg_name}, {s2} steps, {d2:.1f} s, OpenMP over envs",
+            "reference_python": REFERENCE_PYTHON}
+
+
+# ---------------------------------------------------------------------------------------------------------------- one config
+def pmc_notes(cfg_name):
+    """HBM traffic and VALU instruction counts of the dominant kernel from a builder-side `rocprofv3 --pmc` run of this same
+    command (tools/pmc_fast.sh, tools/profile_gpu.sh; copied to profiles/): NOT measured in this process."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(cfg_name, {})
+    except (OSError, ValueError):
+        return {}
+
+
+def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_baseline):
+    from adcraft_amd import _ffi, synthetic, distributed as D
+    from adcraft_amd.engine import StepEngine
+
+    N, K, mean_volume, cvr, no_vol_prob, drift = synthetic.CONFIGS[cfg_name]
+    planes = synthetic.implicit_keyword_planes(N, K, seed=1729 + rank, mean_volume=mean_volume, cvr=cvr, no_vol_prob=no_vol_prob)
+    n_dev = max(_ffi.device_count(), 1)
+    eng = StepEngine(N, K, device_id=local_rank % n_dev, seed=1729, env_id_base=rank * N, max_days=MAX_DAYS,
+                     loss_threshold=1.0e12, drift_enabled=drift, auto_reset=True)
+    eng.set_all_params(planes)
+    eng.reset()
+    eng.sample_actions(0.30, 1.00, args.budget)  # actions resident in HBM before the timed region
+    eng.metrics_enable(True)
+    red = D.MetricReducer(eng, rank, world)      # world > 1: the engine's RCCL communicator (collective bring-up)
+    # stationary keywords: the ideal (max expected) profit per keyword is constant over the episode
+    ideal_nk = eng.ideal_profit(2048)            # (with drift on this is the episode-start value)
+    ideal_k, ideal_pos_k = ideal_nk.sum(axis=0), np.where(ideal_nk <= 0, 1.0, ideal_nk).sum(axis=0)
+
+    def barrier():
+        eng.synchronize()
+        red.barrier()
+
+    for _ in range(warmup):
+        eng.step_device()
+    red.metric_sums(ideal_k * warmup, ideal_pos_k * warmup)       # also brings the collective path up outside the timed region
+    barrier()
+    eng.metrics_reset()
+    eng.profile_enable(True)
+    eng.profile_read()
+    barrier()
     t0 = time.perf_counter()
-    steps = 0
-    auctions = 0
-    while time.perf_counter() - t0 < seconds:
-        out = o.step(bids, 1.0e9)
-        auctions += int(out["volumes"].sum())
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": n_envs * K * steps / dt, "unit": "keyword-steps/s", "cores": cores, "kind": "port",
-            "auctions_per_s": auctions / dt,
-            "sample": f"{n_envs} envs x {K} keywords of {cfg_name}, {steps} steps, {dt:.1f} s, OpenMP over envs"}
+    for s in range(steps):
+        eng.step_device()
+        if world > 1 and (s + 1) % MAX_DAYS == 0:
+            red.metric_sums(ideal_k * (s + 1), ideal_pos_k * (s + 1))     # the single collective of the path, once per episode
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.profile_read()
+    eng.profile_enable(False)
+    profit_c, ideal, ideal_pos, sc = red.metric_sums(ideal_k * steps, ideal_pos_k * steps)
+    elapsed = float(red.allreduce([elapsed], op="max")[0])          # the slowest rank's time
+    _, ranks_in_comm = eng.comm_info()
+    n_gpus = ranks_in_comm if red.backend == "rccl" else world
+
+    units = float(world) * N * K * steps
+    b_alg = BYTES_PER_U[drift] * N * K + BYTES_PER_ENV * N            # algorithmic bytes per launch (one GPU)
+    dom = int(np.argmax(kernel_ms))              # the dominant kernel of the step
+    k_ms = kernel_ms[dom] / max(launches, 1)
+    achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
+    notes = pmc_notes(cfg_name) if dom == 0 else {}
+    res = {
+        "value": units / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+        "env_steps_per_s": float(world) * N * steps / elapsed, "n_gpus": n_gpus,
+        "workload": f"{cfg_name}: {N} envs x {K} keywords per GPU, IMPLICIT keywords, mean_volume {mean_volume}, cvr {cvr}, "
+                    f"no_vol_prob {no_vol_prob}, drift {drift}, budget {'non-binding' if args.budget >= 1e8 else args.budget}, "
+                    f"{MAX_DAYS}-step episodes with auto-reset",
+        "envs_per_gpu": N, "keywords": K,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                     "traffic": notes.get("hbm_bytes_per_launch"),
+                     "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else None),
+                     "kernel": KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches),
+                     "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(KERNEL_NAMES, kernel_ms)},
+                     "algorithmic_bytes_per_launch": b_alg},
+    }
+    valu = notes.get("valu")
+    if valu and launches:
+        # the bound that actually binds on dense keyword sets: VALU issue.  Instruction count: builder-side PMC (see `source`);
+        # time: live, this run.  peak = one wave64 instruction per 2 cycles per SIMD-32 at 2.4 GHz - reachable only by the
+        # full-rate opcodes (profiles/r02_issue_rates.md: compares, converts, min/max, integer multiplies cost 4 cycles)
+        lane_ops = valu["wave_instructions_per_launch"] * 64.0 / (k_ms * 1e-3)
+        res["roofline_valu"] = {"bound": "valu", "achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-instructions/s",
+                                "frac": lane_ops / VALU_PEAK_LANE_OPS, "kernel": KERNEL_NAMES[0], "kernel_ms": k_ms,
+                                "valu_wave_instructions_per_launch": valu["wave_instructions_per_launch"],
+                                "valu_lane_instructions_per_auction": valu.get("valu_lane_instructions_per_auction"),
+                                "source": "instruction count: " + str(notes.get("source_note")) + "; kernel time: HIP events in this run"}
+    akncp_ncp = D.episode_metrics(profit_c, ideal, ideal_pos, sc)
+    res["episode_metric"] = {"AKNCP": akncp_ncp["AKNCP"], "NCP": akncp_ncp["NCP"], "profit_dollars": akncp_ncp["profit"],
+                             "env_steps": akncp_ncp["env_steps"], "episodes": akncp_ncp["episodes"],
+                             "note": "synthetic uniform bids, not a trained agent; envs pooled by keyword index"}
+    if with_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg_name, planes, K, args.cpu_seconds)
+    red.close()
+    eng.close()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------- rank / launcher
+def rehearse_rank(args, rank, world):
+    """--rehearse: everything around the GPU work, without a GPU (tests/test_distributed_cpu.py): the id hand-over, a
+    reduction, the slowest-rank time, the line"""
+    from adcraft_amd import comm, synthetic
+    if args.fail_rank == rank:
+        raise SystemExit(3)
+    uid = comm.exchange_bytes(rank, world, lambda: bytes(range(128)))
+    red = comm.FileReducer(rank, world)
+    seen = red.allreduce(np.eye(world)[rank])
+    elapsed = float(red.allreduce([0.001 * (rank + 1) * args.steps], op="max")[0])
+    red.close()
+    if rank == 0:
+        N, K = synthetic.CONFIGS["cfg4"][:2]
+        print(json.dumps({"metric": "env-steps/sec (envs×keywords auctions/s)", "value": None, "unit": "keyword-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none (rehearsal)",
+                          "config": {"workload": f"cfg4: {N} envs x {K} keywords per GPU (not run: --rehearse)"},
+                          "rehearsal": {"ranks_seen": [int(i) for i in np.nonzero(seen)[0]], "id_bytes": len(uid)}}), flush=True)
+
+
+def run_rank(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse:
+        return rehearse_rank(args, rank, world)
+    main_cfg = args.config or ("cfg2" if world == 1 else "cfg4")
+    also_cfgs = [] if args.no_also or args.config else (["cfg3", "cfg4", "cfg5"] if world == 1 else ["cfg5"])
+    main = run_config(main_cfg, args, rank, world, local_rank, args.steps, args.warmup, with_cpu_baseline=(world == 1 and rank == 0 and not args.no_cpu_baseline))
+    also = {}
+    for c in also_cfgs:
+        r = run_config(c, args, rank, world, local_rank, max(50, min(args.steps, 100)), max(10, min(args.warmup, 20)), with_cpu_baseline=False)
+        also[c] = {k: r[k] for k in ("value", "ms_per_step", "steps", "workload", "roofline", "episode_metric") if k in r}
+        if "roofline_valu" in r:
+            also[c]["roofline_valu"] = r["roofline_valu"]
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec (envs×keywords auctions/s)",
+            "value": main["value"], "unit": "keyword-steps/s",
+            "n_gpus": main["n_gpus"], "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32 cents + f32 (Philox4x32-7 u32)", "data": "synthetic",
+            "config": {"workload": main["workload"], "envs_per_gpu": main["envs_per_gpu"], "keywords": main["keywords"],
+                       "parallelism": f"env-sharded x{main['n_gpus']}",
+                       "collective": ("none on the step path; RCCL all-reduce of the episode-metric vector once per episode "
+                                      "(adc_engine_metrics_allreduce)") if world > 1 else "none (single GPU)"},
+            "env_steps_per_s": main["env_steps_per_s"],
+            "roofline": main["roofline"],
+        }
+        for k in ("roofline_valu", "episode_metric", "cpu_baseline"):
+            if k in main:
+                line[k] = main[k]
+        if also:
+            line["also"] = also
+        print(json.dumps(line), flush=True)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """start args.gpus fresh rank processes (this process never touches a GPU), relay rank 0's line"""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ADCRAFT_JOB_ID=f"bench{os.getpid()}")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's line is a few KB: it fits the pipe, so polling the exit codes first cannot deadlock on it
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):          # a rank failed: the others would wait for it forever
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            sys.stderr.write(f"bench.py: rank exit codes {[p.returncode for p in procs]}\n")
+            import glob
+            import shutil
+            import tempfile
+            for leftover in glob.glob(os.path.join(tempfile.gettempdir(), f"adcraft_comm_{port}_bench{os.getpid()}.*")):
+                shutil.rmtree(leftover, ignore_errors=True) if os.path.isdir(leftover) else os.remove(leftover)
+            raise SystemExit(1)
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    sys.stdout.write(procs[0].stdout.read())
+    sys.stdout.flush()
 
 
 def main():
@@ -54,140 +275,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="cfg2", help="cfg2 (metric config), cfg3, cfg4, cfg5")
+    ap.add_argument("--config", default=None, help="measure only this config (cfg2, cfg3, cfg4, cfg5) instead of the contract's workload")
     ap.add_argument("--budget", type=float, default=1.0e9, help="per-env daily budget in dollars (default: non-binding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary configs")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--rehearse", action="store_true", help="no GPU work: launch, id hand-over and reduction only (CPU test)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    backend = os.environ.get("ADCRAFT_DIST_BACKEND", "nccl")     # "gloo" lets the N>1 path be rehearsed on one GPU
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    red_device = "cuda" if backend == "nccl" else None
-
-    from adcraft_amd import _ffi, synthetic
-    from adcraft_amd.engine import StepEngine
-
-    N, K, mean_volume, cvr, no_vol_prob, drift = synthetic.CONFIGS[args.config]
-    max_days = 60
-    planes = synthetic.implicit_keyword_planes(N, K, seed=1729 + rank, mean_volume=mean_volume, cvr=cvr,
-                                               no_vol_prob=no_vol_prob)
-    n_dev = max(_ffi.device_count(), 1)
-    eng = StepEngine(N, K, device_id=local_rank % n_dev, seed=1729, env_id_base=rank * N, max_days=max_days,
-                     loss_threshold=1.0e12, drift_enabled=drift, auto_reset=True)
-    eng.set_all_params(planes)
-    eng.reset()
-    eng.sample_actions(0.30, 1.00, args.budget)  # actions resident in HBM before the timed region
-    eng.metrics_enable(True)
-
-    from adcraft_amd import distributed as D, experiment_metrics as em
-    # stationary keywords: the ideal (max expected) profit per keyword is constant over the episode
-    ideal_k = eng.ideal_profit(2048).sum(axis=0)      # (with drift on this is the episode-start value)
-
-    def metric_allreduce(steps_done):
-        """the single collective of the path: [sum profit_k | sum ideal_k | scalars], RCCL over xGMI for N>1"""
-        kp, sc = eng.metrics_read()
-        vec = D.pack_metric_vector(kp, ideal_k * steps_done, sc)
-        if dist is not None:
-            vec = D.all_reduce_sum(vec, device=red_device)
-        return vec
-
-    def barrier():
-        eng.synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            if backend == "nccl":
-                torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.step_device()
-    metric_allreduce(args.warmup)       # also brings up the RCCL communicator outside the timed region
-    barrier()
-    eng.metrics_reset()
-    eng.profile_enable(True)
-    eng.profile_read()
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        eng.step_device()
-        if dist is not None and (s + 1) % max_days == 0:
-            metric_allreduce(s + 1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = eng.profile_read()
-    eng.profile_enable(False)
-    totals = metric_allreduce(args.steps)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device or "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        units = float(world) * N * K * args.steps
-        b_alg = BYTES_PER_U[drift] * N * K + BYTES_PER_ENV * N            # algorithmic bytes per launch (one GPU)
-        names = ("k_step_implicit_fast", "k_step_exact_rows (+ step tail)", "k_metric_accumulate")
-        dom = int(np.argmax(kernel_ms))              # the dominant kernel of the step
-        k_ms = kernel_ms[dom] / max(launches, 1)
-        achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
-        traffic, valu = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                pmc_cfg = json.load(open(pmc)).get(args.config, {})
-                traffic = pmc_cfg.get("hbm_bytes_per_launch") if dom == 0 else None
-                valu = pmc_cfg.get("valu") if dom == 0 else None
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "env-steps/sec (envs\u00d7keywords auctions/s)",
-            "value": units / elapsed,
-            "unit": "keyword-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i32 cents + f32 (Philox4x32-10 u32)", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {N} envs x {K} keywords per GPU, IMPLICIT keywords, "
-                                   f"mean_volume {mean_volume}, cvr {cvr}, no_vol_prob {no_vol_prob}, drift {drift}, "
-                                   f"budget {'non-binding' if args.budget >= 1e8 else args.budget}, {max_days}-step episodes with auto-reset",
-                       "envs_per_gpu": N, "keywords": K, "parallelism": f"env-sharded x{world}"},
-            "env_steps_per_s": float(world) * N * args.steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": names[dom], "kernel_ms": k_ms, "launches": int(launches),
-                         "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(names, kernel_ms)},
-                         "algorithmic_bytes_per_launch": b_alg},
-        }
-        if valu and launches:
-            # why the HBM fraction is low on dense configs: the kernel is VALU-issue-bound (static PMC counts of this
-            # workload from profiles/pmc_traffic.json, divided by the live kernel time)
-            line["roofline"]["issue"] = {"valu_wave_instructions_per_launch": valu["wave_instructions_per_launch"],
-                                         "valu_wave_instructions_per_s": valu["wave_instructions_per_launch"] / (k_ms * 1e-3),
-                                         "valu_lane_instructions_per_auction": valu.get("valu_lane_instructions_per_auction")}
-        profit_c, ideal, sc = D.unpack_metric_vector(totals, K)
-        akncp, ncp = em.akncp_ncp_from_sums(profit_c / 100.0, ideal)
-        line["episode_metric"] = {"AKNCP": akncp, "NCP": ncp, "profit_dollars": float(sc[0]) / 100.0,
-                                  "env_steps": int(sc[1]), "episodes": int(sc[2]),
-                                  "note": "synthetic uniform bids, not a trained agent"}
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.config, planes, K, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":

@@ -39,7 +39,8 @@ typedef enum adc_status {
     ADC_EHIP = -2,     /* HIP runtime failure or no device (-> RuntimeError) */
     ADC_ENOMEM = -3,   /* device or host allocation failed (-> MemoryError) */
     ADC_ESTATE = -4,   /* call not valid in the current state, e.g. step before reset */
-    ADC_ETYPE = -5     /* wrong element type for a reducer shim (-> TypeError, see adcraft.rust tests) */
+    ADC_ETYPE = -5,    /* wrong element type for a reducer shim (-> TypeError, see adcraft.rust tests) */
+    ADC_ERCCL = -6     /* librccl missing, or an RCCL call of the metric all-reduce failed (-> RuntimeError) */
 } adc_status;
 
 /* keyword model: which of the reference's two Keyword subclasses the engine simulates */
@@ -231,6 +232,27 @@ int adc_engine_profile_enable(adc_engine *e, int enabled);
 /* kernel_ms_total[3] = summed durations of {fast pass, exact pass + step tail, metric accumulate} over `launches`
  * steps since enable / the last read; resets the counters */
 int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, int64_t *launches);
+
+/* ---- multi-GPU: the one collective of the path ----------------------------------------------- */
+/* Envs shard over the GPUs of a node, one process (one engine) per GPU; nothing on the step path communicates.  The
+ * episode-level metric (compute_AKNCP / compute_NCP, adcraft/experiment_utils/experiment_metrics.py:64-83) needs sums over
+ * ALL envs: one RCCL all-reduce (sum) of 3K + 8 doubles on the engine's stream, over xGMI.
+ *   rank 0:      adc_comm_get_unique_id(id)  and hands the 128 bytes to the other ranks (file, socket, ... - caller's choice)
+ *   every rank:  adc_engine_comm_init(engine, id, rank, world_size)         (collective)
+ *   per report:  adc_engine_metrics_allreduce(engine, ...)                  (collective)
+ * Without a communicator (a single GPU) the calls return the local sums.  librccl.so is opened on first use. */
+#define ADC_COMM_ID_BYTES 128
+int adc_comm_get_unique_id(uint8_t *id_bytes /* [ADC_COMM_ID_BYTES] */);
+int adc_engine_comm_init(adc_engine *e, const uint8_t *id_bytes, int32_t rank, int32_t world_size);
+int adc_engine_comm_destroy(adc_engine *e);
+int adc_engine_comm_info(adc_engine *e, int32_t *rank, int32_t *world_size);
+/* out_3k8[0..K) = keyword profit in cents, [K..2K) = ideal profit, [2K..3K) = ideal profit with <= 0 -> 1 per entry (the
+ * denominator compute_AKNCP uses, :71-75), [3K..3K+8) = {profit_cents, env_steps, episodes, truncations, ...}: sums over
+ * steps, envs and ranks.  The ideal sums are the engine's own (adc_engine_ideal_step) when it accumulates them; otherwise
+ * this rank's contribution may be passed as host vectors ideal_k / ideal_pos_k ([K] doubles each, NULL = zeros). */
+int adc_engine_metrics_allreduce(adc_engine *e, const double *ideal_k, const double *ideal_pos_k, double *out_3k8);
+/* sum (op 0) or max (op 1) of `count` host doubles over the ranks, in place (a barrier is count = 1) */
+int adc_engine_comm_allreduce_f64(adc_engine *e, double *inout, int32_t count, int32_t op);
 
 /* ---- episode metrics (adcraft/experiment_utils/experiment_metrics.py:64-83) ----------------------- */
 int adc_engine_metrics_enable(adc_engine *e, int enabled);

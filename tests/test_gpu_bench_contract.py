@@ -20,7 +20,7 @@ def _run(*args):
 def test_bench_line_contract():
     d = _run("--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1.0")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "also"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -35,12 +35,39 @@ def test_bench_line_contract():
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.01           # the kernel runs inside the timed region
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["single_thread"]["cores"] == 1 and 0 < c["single_thread"]["value"] <= c["value"] * 1.5
+    assert c["reference_python"]["value"] > 0 and "provenance" in c["reference_python"]
     assert d["value"] > 100 * c["value"]
     assert 0 < d["episode_metric"]["NCP"] < 2
+    if r["traffic"] is not None:
+        assert r["traffic_source"]                      # a number not measured in this process says where it is from
+    # the largest single-GPU config and the per-GPU shards of the 8-GPU configs, measured in the same run
+    a = d["also"]
+    assert set(a) == {"cfg3", "cfg4", "cfg5"}
+    assert a["cfg3"]["steps"] >= 50 and a["cfg3"]["roofline"]["algorithmic_bytes_per_launch"] == 16384 * 1024 * 56 + 26 * 16384
+    assert a["cfg3"]["value"] == pytest.approx(16384 * 1024 / (a["cfg3"]["ms_per_step"] * 1e-3), rel=1e-6)
+    assert a["cfg3"]["roofline"]["frac"] > d["roofline"]["frac"]          # the sparse config is the HBM-heavy one
 
 
 def test_bench_other_configs_run():
     d = _run("--config", "cfg5", "--steps", "4", "--warmup", "1", "--no-cpu-baseline")
     assert "drift True" in d["config"]["workload"] and d["roofline"]["algorithmic_bytes_per_launch"] == 2048 * 1024 * 68 + 26 * 2048
-    d = _run("--budget", "50", "--steps", "4", "--warmup", "2", "--no-cpu-baseline")
-    assert d["roofline"]["kernel"].startswith("k_step_exact_rows")
+    assert "also" not in d
+    d = _run("--budget", "50", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-also")
+    assert "k_step_exact_rows" in d["roofline"]["kernel"]
+
+
+def test_bench_two_ranks_on_one_gpu_with_the_stand_in_reduction():
+    """`--gpus 2` starts two rank processes; on a one-GPU box both engines share the device, so the reduction goes
+    through the file stand-in (RCCL refuses two ranks on one device; the RCCL call itself is covered at world size 1 by
+    test_gpu_device_resident.py).  Everything else - sharding by global env id, the per-episode reduction inside the timed
+    region, the slowest rank's time, rank 0's line - is the N > 1 path as the driver runs it."""
+    env = dict(os.environ, ADCRAFT_DIST_BACKEND="file")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "61", "--warmup", "2",
+                                   "--config", "cfg5"], text=True, cwd=ROOT, timeout=900, env=env)
+    d = json.loads([ln for ln in out.strip().splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 2048 * 1024 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["episode_metric"]["env_steps"] == 2 * 2048 * 61

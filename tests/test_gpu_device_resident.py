@@ -139,3 +139,40 @@ def test_c_program_runs_against_the_library(tmp_path):
                            "-L", libdir, "-ladcraft_hip", "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.check_output([exe], text=True)
     assert out.strip().endswith("ok") and "step 2 env 3" in out and "terminated" in out
+
+
+def test_rccl_allreduce_behind_the_c_abi_world_size_one():
+    """adc_comm_get_unique_id -> adc_engine_comm_init(rank 0 of 1) -> adc_engine_metrics_allreduce: the RCCL calls of the
+    path's one collective run (librccl loaded on first use, ncclAllReduce on the engine's stream over the device-resident
+    accumulators) and return this rank's own sums; without a communicator the same entry point returns them too."""
+    import adcraft_amd.engine as eng
+    from tests import helpers as H
+    N, K = 6, 70
+    planes = H.implicit_params(N, K, seed=51)
+    e = eng.StepEngine(N, K, seed=4, max_days=3, auto_reset=True)
+    e.set_all_params(planes)
+    e.reset()
+    e.metrics_enable(True)
+    e.metrics_reset()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        e.step(rng.uniform(0.3, 1.0, (N, K)).astype(np.float32), 1e9)
+    kp, sc = e.metrics_read()
+    ideal, ideal_pos = np.arange(K, dtype=np.float64) - 3.0, np.arange(K, dtype=np.float64) + 1.0
+    alone = e.metrics_allreduce(ideal, ideal_pos)                   # no communicator: local sums
+    assert e.comm_info() == (0, 1)
+    uid = e.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    e.comm_init(uid, 0, 1)
+    assert e.comm_info() == (0, 1)
+    with pytest.raises(AssertionError):
+        e.comm_init(uid, 0, 1)                                      # one communicator per engine
+    got = e.metrics_allreduce(ideal, ideal_pos)                     # through ncclAllReduce
+    for a, b in zip(alone, got):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got[0], kp.astype(np.float64)) and np.array_equal(got[3], sc.astype(np.float64))
+    assert np.array_equal(got[1], ideal) and np.array_equal(got[2], ideal_pos)
+    assert e.comm_allreduce([1.5, -2.0]).tolist() == [1.5, -2.0] and e.comm_allreduce([3.0], op="max").tolist() == [3.0]
+    e.comm_destroy()
+    assert e.comm_info() == (0, 1)
+    e.close()
