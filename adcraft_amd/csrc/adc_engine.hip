@@ -48,8 +48,8 @@
 namespace adck {
 #include "parts/common.inc"
 #include "parts/kernel_fast.inc"
-#include "parts/kernel_exact_serial.inc"
 #include "parts/kernel_exact_rows.inc"
+#include "parts/kernel_exact_serial.inc"
 #include "parts/kernel_explicit_fast.inc"
 #include "parts/kernels_misc.inc"
 #include "parts/kernels_policy.inc"

@@ -165,8 +165,14 @@ class BiddingSimulationVectorEnv:
             infos = {}
             done = term | trunc
             if self.autoreset and done.any():
+                # same-step autoreset (metadata["autoreset_mode"]): the terminal observation goes to infos["final_obs"], and
+                # obs carries the first observation of the next episode - all zeros, as reset() returns it
+                # (gymnasium_kw_env.py:340-342); the engine has already restarted those envs
                 infos["final_obs"] = obs[done].copy()
                 infos["_final_obs"] = done.copy()
+                if not obs.flags.writeable or not self.copy:
+                    obs = obs.copy()
+                obs[done] = 0.0
             return obs, reward, term, trunc, infos
         bids, budget = self._split_actions(actions)
         out = self._engine.step(bids, budget, copy=False)
@@ -190,6 +196,10 @@ class BiddingSimulationVectorEnv:
             # reset() without a seed does in the reference, gymnasium_kw_env.py:303,327-328)
             infos["final_obs"] = {k: v[done].copy() for k, v in obs.items()}
             infos["_final_obs"] = done.copy()
+            for k in obs:                       # obs of a finished env = the reset observation of its next episode: zeros
+                if not self.copy:
+                    obs[k] = obs[k].copy()
+                obs[k][done] = 0
         return obs, reward, term, trunc, infos
 
     # device-resident stepping for policies that live on the GPU (no PCIe on the step path)
@@ -271,9 +281,7 @@ class SB3VecEnvAdapter:
             final = infos["final_obs"]
             for j, i in enumerate(np.nonzero(dones)[0]):
                 out_infos[i]["terminal_observation"] = final[j]
-            obs = obs.copy()
-            obs[dones] = 0.0            # the reset observation is all zeros (gymnasium_kw_env.py:340-342)
-        return obs, rew.astype(np.float32), dones, out_infos
+        return obs, rew.astype(np.float32), dones, out_infos      # (obs of finished envs is already the zero reset observation)
 
     def step(self, actions):
         self.step_async(actions)

@@ -152,6 +152,9 @@ def test_vector_env_matches_single_envs(pkg):
     vec.step({"keyword_bids": bids})
     vobs, rew, term, trunc, infos = vec.step({"keyword_bids": bids})
     assert term.all() and infos["_final_obs"].all() and (infos["final_obs"]["days_passed"] == 3).all()
+    # same-step autoreset: the terminal observation is in infos["final_obs"]; obs is the next episode's reset observation
+    assert infos["final_obs"]["impressions"].sum() > 0
+    assert all((v == 0).all() for v in vobs.values())
     vobs, *_ = vec.step({"keyword_bids": bids})
     assert (vobs["days_passed"] == 1).all()          # autoreset restarted the episodes
     vec.close()
@@ -175,6 +178,10 @@ def test_flat_layout_and_adaptors(pkg):
     obs_list, infos = r.vector_reset(seeds=[7] * N)
     o2, rew, term, trunc, infos = r.vector_step([a for a in act])
     assert len(o2) == N and np.array_equal(np.stack(o2), of) and len(rew) == N
+    o2b, _, term2, _, infos2 = f.step(act)                 # the flat path: same-step autoreset too (max_days = 2)
+    assert term2.all() and (o2b == 0).all() and infos2["final_obs"].shape == (N, 5 * K + 2) and (infos2["final_obs"][:, 2 * K + 1] == 2).all()
+    f.reset(seed=7)
+    f.step(act)
     s = SB3VecEnvAdapter(mk(True))
     s.seed(7)
     o3 = s.reset()

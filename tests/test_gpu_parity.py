@@ -479,10 +479,11 @@ def test_exact_pass_sparse_and_large_cells(amd):
     _run_vs_oracle(amd, 2, 24, planes, steps=2, budget=700.0)
 
 
-def test_metric_accumulators_with_hinted_exact_pass(amd):
-    """metric sums stay exact when envs alternate between fast pass, re-run by the row kernel, and hinted steps"""
-    N, K = 6, 300
-    planes = H.implicit_params(N, K, seed=33)
+@pytest.mark.parametrize("N,K,vol", [(6, 300, 128), (3, 2100, 12)])
+def test_metric_accumulators_with_hinted_exact_pass(amd, N, K, vol):
+    """metric sums stay exact when envs alternate between fast pass, re-run by the row kernel (K <= 2048) or by the serial
+    walker (beyond), and hinted steps"""
+    planes = H.implicit_params(N, K, seed=33, mean_volume=vol)
     e = amd.StepEngine(N, K, seed=8)
     e.set_all_params(planes)
     e.reset()
