@@ -241,12 +241,19 @@ ADC_HD int32_t laplace_cents(uint32_t w, float loc, float scale)
 }
 
 // event <=> (uint64)word < threshold; threshold = round(p * 2^32) in [0, 2^32]
+// (float32 throughout, exactly: p 2^32 is a power-of-two scaling; at or above 2^23 it is already an integer, below it
+// x + 0.5 is representable - so this is floor(p 2^32 + 0.5) as a double would compute it)
+ADC_HD float bernoulli_threshold_f32(float p)
+{
+    if (!(p > 0.0f)) return 0.0f;                        // (NaN too)
+    const float x = p * 4294967296.0f;
+    if (!(x < 4294967296.0f)) return 4294967296.0f;
+    return x >= 8388608.0f ? x : __builtin_floorf(x + 0.5f);
+}
 ADC_HD uint64_t bernoulli_threshold(float p)
 {
-    double t = __builtin_floor((double)p * 4294967296.0 + 0.5);
-    if (!(t > 0.0)) return 0;
-    if (t > 4294967296.0) t = 4294967296.0;
-    return (uint64_t)t;
+    const float t = bernoulli_threshold_f32(p);
+    return t >= 4294967296.0f ? 4294967296ull : (uint64_t)(uint32_t)t;
 }
 ADC_HD bool bernoulli(uint32_t w, uint64_t threshold) { return (uint64_t)w < threshold; }
 // the same test with the threshold saturated to 32 bits: 0xFFFFFFFF can only come from T = 2^32 (p = 1; the
@@ -301,13 +308,24 @@ ADC_HD uint32_t rescale_multiplier(uint64_t range)
     return (uint32_t)m;
 }
 
+// rescale_multiplier of a range given as the float32 it converts to
+ADC_HD uint32_t rescale_multiplier_f32(float range)
+{
+    if (!(range > 0.0f)) return 0u;
+    float m = __builtin_floorf(72057594037927936.0f / range);
+    m = m < 4294967040.0f ? m : 4294967040.0f;
+    return (uint32_t)m;
+}
+
 ADC_HD AuctionLaw make_auction_law(float bctr)
 {
-    const uint64_t t = bernoulli_threshold(bctr);
+    // T is an integer-valued float32 <= 2^32, so (float)T is T itself and (float)(2^32 - T) is the float32 difference
+    // (one rounding of the same integer either way): no 64-bit integer conversions
+    const float t = bernoulli_threshold_f32(bctr);
     AuctionLaw a;
-    a.t32 = saturate_threshold(t);
-    a.m_click = rescale_multiplier(t);
-    a.m_noclick = rescale_multiplier(4294967296ull - t);
+    a.t32 = t >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)t;
+    a.m_click = rescale_multiplier_f32(t);
+    a.m_noclick = rescale_multiplier_f32(4294967296.0f - t);
     return a;
 }
 
@@ -327,11 +345,24 @@ ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 // with u = (2 mag + 1) / 2^24 and e(mag) = -log u by the table above.  X = loc + |scale| z and round(100 X) are then
 // non-decreasing in v (every step is a correctly rounded monotone operation), so {v : bid > cents(v)} is an interval - which
 // is what lets the step kernels resolve an auction by comparing its word with per-keyword thresholds.
+// neg_log_u24 with its argument already a float (an odd integer below 2^24, exactly representable)
+ADC_HD float neg_log_f24(float w24, const LogTableEntry *tab)
+{
+    const uint32_t bits = float_to_bits(w24);
+    const float ef = (float)((int)(bits >> 23) - 151);
+    const uint32_t mant = bits & 0x007FFFFFu;
+    const LogTableEntry t = tab[mant >> 15];
+    float r = fma32(t.slope, (float)(mant & 0x7FFFu), t.value);
+    r = fma32(ef, -2.12194440e-4f, r);
+    r = fma32(ef, 0.693359375f, r);
+    return -r;
+}
+
 ADC_HD float laplace_deviate_from_v(uint32_t v24, const LogTableEntry *tab)
 {
     const uint32_t neg_mask = 0u - (v24 >> 23);                                  // all ones on the positive side
     const uint32_t mag = (v24 ^ neg_mask) & 0x007FFFFFu;
-    const float e = neg_log_u24((mag << 1) | 1u, tab);                          // e > 0
+    const float e = neg_log_f24(fma32((float)mag, 2.0f, 1.0f), tab);            // 2 mag + 1 < 2^24: exact in float32; e > 0
     return bits_to_float(float_to_bits(e) ^ (~neg_mask & 0x80000000u));         // negative side: -e
 }
 
@@ -345,10 +376,13 @@ ADC_HD int32_t signed_cents_from_v(uint32_t v24, float loc, float scale, const L
     return (int32_t)c;
 }
 
+// |signed_cents_from_v|: rint and the clamp are odd-symmetric, so |round(100 x)| = round(100 |x|)
 ADC_HD int32_t competitor_cents_from_v(uint32_t v24, float loc, float scale, const LogTableEntry *tab)
 {
-    const int32_t c = signed_cents_from_v(v24, loc, scale, tab);
-    return c < 0 ? -c : c;
+    const float x = fma32(__builtin_fabsf(scale), laplace_deviate_from_v(v24, tab), loc);
+    float c = __builtin_rintf(__builtin_fabsf(x) * 100.0f);
+    c = c < kMoneyMaxCents ? c : kMoneyMaxCents;          // (NaN -> 1e9: a NaN parameter never wins)
+    return (int32_t)c;
 }
 
 // the 24-bit uniform of an auction word (click decided, offset rescaled inside its sub-interval)
@@ -364,6 +398,16 @@ ADC_HD uint32_t auction_uniform24(uint32_t w, const AuctionLaw &a, bool &click)
 // adcraft/synthetic_kw_helpers.py:167-170).  The single word 2^32 - 1 never wins (revision 2): it keeps every threshold of
 // the word-space form of this test (k_step_implicit_fast) within 32 bits, at a cost of 2^-32 in win probability.
 ADC_HD bool auction_wins(uint32_t w, int32_t bid_c, int32_t comp_c) { return bid_c > comp_c && w != 0xFFFFFFFFu; }
+
+// auction_outcome for callers that apply auction_wins right away: the click of the word 2^32 - 1 (the only word the
+// saturated threshold 0xFFFFFFFF = "always" is needed for) is immaterial because that word never wins
+ADC_HD int32_t auction_outcome_unless_top_word(uint32_t w, const AuctionLaw &a, float loc, float scale, const LogTableEntry *tab, bool &click)
+{
+    click = w < a.t32;
+    const uint32_t d = click ? w : w - a.t32;
+    const uint32_t v = mulhi32(d, click ? a.m_click : a.m_noclick);
+    return competitor_cents_from_v(v < 0x00FFFFFFu ? v : 0x00FFFFFFu, loc, scale, tab);
+}
 
 ADC_HD int32_t auction_outcome(uint32_t w, const AuctionLaw &a, float loc, float scale, const LogTableEntry *tab, bool &click)
 {
