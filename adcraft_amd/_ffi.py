@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 ADC_OK, ADC_EINVAL, ADC_EHIP, ADC_ENOMEM, ADC_ESTATE, ADC_ETYPE, ADC_ERCCL = 0, -1, -2, -3, -4, -5, -6
-MODEL_IMPLICIT, MODEL_EXPLICIT = 0, 1
+MODEL_IMPLICIT, MODEL_EXPLICIT, MODEL_IMPLICIT_GENERAL = 0, 1, 2
 P_VOL_MEAN, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT = range(9)
 (BUF_PARAMS, BUF_BIDS, BUF_BUDGET, BUF_IMPRESSIONS, BUF_CLICKS, BUF_CONVERSIONS, BUF_COST, BUF_REVENUE, BUF_REWARD,
  BUF_CUM_PROFIT, BUF_DAYS, BUF_TERMINATED, BUF_TRUNCATED, BUF_METRIC_PROFIT, BUF_METRIC_SCALARS, BUF_FLAT_OBS) = range(16)
@@ -108,6 +108,7 @@ def lib():
         "adc_engine_step_flat": ([vp, vp, vp, vp, vp, vp], C.c_int),
         "adc_engine_step_replay": ([vp, vp, vp, C.POINTER(Tape), C.POINTER(StepOut)], C.c_int),
         "adc_engine_update_keywords": ([vp], C.c_int),
+        "adc_engine_set_general_model": ([vp, i32, f32, i32], C.c_int),
         "adc_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),
         "adc_host_free": ([vp], None),
         "adc_engine_device_buffer": ([vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)], C.c_int),

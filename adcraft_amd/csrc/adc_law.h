@@ -35,7 +35,11 @@ namespace adc {
 //           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
-enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8, ST_AGENT = 9 };
+// GENERAL (the reference's default ImplicitKeyword): call (64 t + b/4, ST_GBIDDERS) word b%4 = participation coin of bidder b in
+//           sub-timestep t; call (j, ST_GBID | (b/4) << 8) word b%4 = the bid of bidder b in auction j;
+//           call (j, ST_GCLICK) = {click, conversion, revenue} words of auction j.
+enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8, ST_AGENT = 9,
+                        ST_GBIDDERS = 10, ST_GBID = 11, ST_GCLICK = 12 };
 constexpr int kTimesteps = 24;          // adcraft/bidding_simulation.py:213
 constexpr int kVolumeMax = 1 << 20;
 constexpr float kMoneyMaxCents = 1.0e9f;
@@ -551,12 +555,13 @@ ADC_HD double cents_to_dollars_f64(int cents)
 // exhaustively by tests/test_oracle_scalar.py::test_cents_to_dollars_is_the_ieee_quotient); larger amounts divide.
 ADC_HD float cents_to_dollars_f32(long long cents)
 {
-    const float a = (float)cents;
-    if (cents > -16777216ll && cents < 16777216ll) {
+    const unsigned long long mag = (unsigned long long)(cents < 0 ? -cents : cents);
+    if (mag < 16777216ull) {                              // one 64-bit compare, then 32-bit arithmetic
+        const float a = (float)(int)cents;
         const float q0 = a * 0.01f;
         return fma32(fma32(-q0, 100.0f, a), 0.01f, q0);
     }
-    return a / 100.0f;
+    return (float)cents / 100.0f;
 }
 
 ADC_HD float clamp01(float v) { v = v > 0.0f ? v : 0.0f; return v < 1.0f ? v : 1.0f; }

@@ -124,6 +124,10 @@ class StepEngine:
         check(self._lib.adc_engine_set_limits(self._h, int(max_days), float(loss_threshold)))
         self.max_days = int(max_days)
 
+    def set_general_model(self, max_bidders=30, participation_rate=0.6, num_winners=1):
+        """model=2 (the reference's default ImplicitKeyword): bidder pool and number of winning placements"""
+        check(self._lib.adc_engine_set_general_model(self._h, int(max_bidders), float(participation_rate), int(num_winners)))
+
     def set_drift(self, enabled, drift=(0.03, 0.03, 0.03)):
         check(self._lib.adc_engine_set_drift(self._h, 1 if enabled else 0, float(drift[0]), float(drift[1]), float(drift[2])))
 

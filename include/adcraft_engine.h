@@ -47,8 +47,14 @@ typedef enum adc_status {
 typedef enum adc_model {
     ADC_MODEL_IMPLICIT = 0,  /* ImplicitKeyword: literal 2nd-price auction vs one sampled competitor bid
                                 (adcraft/synthetic_kw_classes.py:578-646, gymnasium_kw_utils.py:169-195) */
-    ADC_MODEL_EXPLICIT = 1   /* ExplicitKeyword: sigmoid impression rate + Binomial + parametric cost
+    ADC_MODEL_EXPLICIT = 1,  /* ExplicitKeyword: sigmoid impression rate + Binomial + parametric cost
                                 (adcraft/synthetic_kw_classes.py:457-575, gymnasium_kw_utils.py:67-96) */
+    ADC_MODEL_IMPLICIT_GENERAL = 2   /* the DEFAULT ImplicitKeyword (not the env's single-competitor form): B ~ Binomial(max_bidders,
+                                participation_rate) bidders drawn once per (sub-timestep, keyword) call, raw Laplace(loc, scale) bids,
+                                the literal top-(w+n) clearing of nth_price_auction with n = 2: won iff the bid exceeds the (w)-th
+                                highest competitor bid, price = the bid just below ours; float64 money
+                                (adcraft/synthetic_kw_classes.py:610-686, adcraft/synthetic_kw_helpers.py:116-180).
+                                Parameter planes A / B = bid_loc / bid_scale; pool and winners: adc_engine_set_general_model */
 } adc_model;
 
 /* parameter planes (float32).  Slots 2,3 depend on the model. */
@@ -123,8 +129,8 @@ typedef enum adc_buffer {
 typedef struct adc_tape {
     const int32_t *volumes;        /* [N*K] auction volume of each keyword this step */
     const int32_t *bid_cents;      /* IMPLICIT: competitor bids in cents, n per visited cell */
-    const int32_t *x_impressions;  /* EXPLICIT: Binomial result per visited cell */
-    const double *x_cost;          /* EXPLICIT: per-impression costs */
+    const int32_t *x_impressions;  /* EXPLICIT: Binomial result per visited cell; IMPLICIT_GENERAL: bidders of the cell */
+    const double *x_cost;          /* EXPLICIT: per-impression costs; IMPLICIT_GENERAL: bids, bidders x auctions per cell (bidder-major) */
     const uint8_t *click;          /* one per won auction (IMPLICIT) / per cost entry incl. phantom (EXPLICIT) */
     const uint8_t *conv;           /* one per paid click */
     const int32_t *rev_cents;      /* one per conversion */
@@ -205,6 +211,9 @@ int adc_engine_step_flat(adc_engine *e, const float *flat_actions, float *flat_o
 /* replay a recorded tape instead of the engine's own random stream (parity mode) */
 int adc_engine_step_replay(adc_engine *e, const float *bids_nk, const float *budget_n, const adc_tape *tape,
                            adc_step_out *out);
+/* ADC_MODEL_IMPLICIT_GENERAL: the bidder pool (ImplicitKeyword._bidder_distribution_init defaults 30, 0.6) and the number of
+ * winning placements (ImplicitKeyword.auction's n_winners, default 1); max_bidders in [0, 252], num_winners in {1, 2} */
+int adc_engine_set_general_model(adc_engine *e, int32_t max_bidders, float participation_rate, int32_t num_winners);
 /* BiddingSimulation.update_keywords() called directly (gymnasium_kw_env.py:114-158) */
 int adc_engine_update_keywords(adc_engine *e);
 

@@ -45,10 +45,14 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1 };
+enum { ORC_IMPLICIT = 0, ORC_EXPLICIT = 1, ORC_IMPLICIT_GENERAL = 2 };
 enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT };
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
-enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8 };
+enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8,
+       ST_AGENT = 9, ST_GBIDDERS = 10, ST_GBID = 11, ST_GCLICK = 12 };
+/* IMPLICIT_GENERAL (the reference's default ImplicitKeyword): call (64 t + b/4, ST_GBIDDERS) word b%4 = participation coin of
+ * bidder b in sub-timestep t; call (j, ST_GBID | (b/4) << 8) word b%4 = the bid of bidder b in auction j; call (j, ST_GCLICK) =
+ * {click, conversion, revenue} words of auction j. */
 /* Stream layout (revision 2): call (0, ST_VOL, k/4) holds the volume words of keywords 4(k/4)..+3 (word k%4).
  * IMPLICIT: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the click (word < T) and,
  * rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome); the word 2^32-1 never wins;
@@ -456,13 +460,18 @@ typedef struct {
     float imp_thresh;        /* EXPLICIT impression_thresh (0.05 in the env, gymnasium_kw_utils.py:81) */
     int32_t auto_reset;      /* vector form: done envs restart (day=0, cum=0) after reporting */
     int32_t threads;         /* OpenMP threads over envs (cpu_baseline); 0/1 = serial */
+    /* IMPLICIT_GENERAL: the bidder pool of ImplicitKeyword._bidder_distribution_init (synthetic_kw_classes.py:659-665) and the
+     * number of winning placements of the auction (ImplicitKeyword.auction's n_winners, :623) */
+    int32_t max_bidders;     /* default 30 */
+    float participation_rate;/* default 0.6 */
+    int32_t num_winners;     /* default 1 */
 } orc_config;
 
 typedef struct {             /* TAPE source: flat per-call tapes + cursors (advanced by the step) */
     const int32_t *volumes;      /* [N][K] */
     const int32_t *bid_cents;    /* IMPLICIT: competitor bids, n per visited cell */
-    const int32_t *x_impressions;/* EXPLICIT: Binomial result per visited cell */
-    const double *x_cost;        /* EXPLICIT: per-impression costs */
+    const int32_t *x_impressions;/* EXPLICIT: Binomial result per visited cell; IMPLICIT_GENERAL: bidders of the cell */
+    const double *x_cost;        /* EXPLICIT: per-impression costs; IMPLICIT_GENERAL: bids, bidders x auctions per cell */
     const uint8_t *click, *conv;
     const int32_t *rev_cents;
     int64_t cur_bid, cur_ximp, cur_xcost, cur_click, cur_conv, cur_rev;  /* in/out */
@@ -628,6 +637,78 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                 o->cost_cents[base + k] += cell_cost;
                 remaining_d -= cell_sum_d;                      /* bidding_simulation.py:225 (rust.sum_list: left to right) */
                 if (remaining_d <= 0.0) stop = 1;               /* :230-233 */
+            } else if (c->model == ORC_IMPLICIT_GENERAL) {
+                /* the reference's default ImplicitKeyword (synthetic_kw_classes.py:610-686): B bidders for the whole call,
+                 * raw Laplace bids, nth_price_auction(bid, other_bids, n=2, num_winners) (synthetic_kw_helpers.py:116-180)
+                 * literally: top (w+n) bids per auction ascending (zero bids appended when there are fewer bidders),
+                 * index = searchsorted left, won iff index > n, price = sorted[index - (n-1)].  Money is float64. */
+                const float loc = P(s, c, P_A, env, k), scale = P(s, c, P_B, env, k);
+                const double bid_d = (double)bid_c / 100.0;
+                const int32_t top = c->num_winners + 2;
+                double budget = remaining_d, cell_cost_sum = 0.0;
+                int64_t cell_rev_c = 0;
+                int32_t imps = 0, paid = 0, convs = 0;
+                int broke = 0;
+                int32_t B;
+                if (use_tape) B = tape->x_impressions[tape->cur_ximp++];
+                else {
+                    const uint64_t t_part = orc_bernoulli_threshold(c->participation_rate);
+                    B = 0;
+                    for (int32_t b = 0; b < c->max_bidders; ++b) {
+                        uint32_t w[4];
+                        draw(key, (uint32_t)(64 * t + (b >> 2)), ST_GBIDDERS, (uint32_t)k, tick, w);
+                        if ((uint64_t)w[b & 3] < t_part) ++B;
+                    }
+                }
+                const int32_t width = B > top ? B : top;
+                double *row = (double *)malloc(sizeof(double) * (size_t)width);
+                const int64_t bids_base = use_tape ? tape->cur_xcost : 0;
+                int64_t click_cur = use_tape ? tape->cur_click : 0;
+                for (int32_t i = 0; i < n; ++i) {
+                    const uint32_t j = (uint32_t)(j0 + i);
+                    int32_t m = 0;
+                    for (int32_t z = 0; z < top - B; ++z) row[m++] = 0.0;            /* :156-161 zero bids */
+                    for (int32_t b = 0; b < B; ++b) {
+                        if (use_tape) row[m++] = tape->x_cost[bids_base + (int64_t)b * n + i];      /* (bidders, auctions) as drawn */
+                        else {
+                            uint32_t w[4];
+                            draw(key, j, (uint32_t)ST_GBID | ((uint32_t)(b >> 2) << 8), (uint32_t)k, tick, w);
+                            const uint32_t v = w[b & 3] >> 8;
+                            const float zf = v < 0x00800000u ? -orc_neg_log_u24(2u * v + 1u) : orc_neg_log_u24(2u * (0x00FFFFFFu - v) + 1u);
+                            row[m++] = (double)fmaf(fabsf(scale), zf, loc);          /* rng.laplace(bid_loc, bid_scale), :681-686 */
+                        }
+                    }
+                    qsort(row, (size_t)m, sizeof(double), cmp_f64);
+                    const double *top_n = row + (m - top);                            /* the top (w+n), ascending (:152-155) */
+                    int32_t index = 0;
+                    while (index < top && top_n[index] < bid_d) ++index;              /* :167 searchsorted, side="left" */
+                    if (!(index > 2)) continue;                                       /* :170 */
+                    const double cost = top_n[index - 1];                             /* :173-175, n = 2 */
+                    ++imps;
+                    uint32_t w3[4] = {0, 0, 0, 0};
+                    if (!use_tape) draw(key, j, ST_GCLICK, (uint32_t)k, tick, w3);
+                    const int clicked = use_tape ? tape->click[click_cur + imps - 1] : ((uint64_t)w3[0] < t_click);
+                    if (!clicked || broke) continue;
+                    if (budget >= cost) {                                             /* bidding_simulation.py:97-104 */
+                        budget -= cost; cell_cost_sum += cost; ++paid;
+                        o->cost[base + k] += cost;
+                        const int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w3[1] < t_conv);
+                        if (conv) {
+                            const int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++] : orc_revenue_cents_tab(w3[2], rev_mu, rev_sd);
+                            ++convs;
+                            o->revenue_cents[base + k] += rev;
+                            cell_rev_c += rev;
+                        }
+                    } else broke = 1;
+                }
+                free(row);
+                if (use_tape) { tape->cur_xcost += (int64_t)B * n; tape->cur_click += imps; }
+                o->impressions[base + k] += imps;
+                o->clicks[base + k] += paid;
+                o->conversions[base + k] += convs;
+                profit_k[k] += (double)cell_rev_c / 100.0 - cell_cost_sum;
+                remaining_d -= cell_cost_sum;
+                if (remaining_d <= 0.0) stop = 1;
             } else {
                 /* EXPLICIT cell: synthetic_kw_classes.py:535-538,514-518 then bidding_simulation.py:94-117 */
                 const float bid_d = (float)((double)bid_c / 100.0);

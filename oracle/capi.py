@@ -7,7 +7,7 @@ import numpy as np
 from . import build as _build
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-IMPLICIT, EXPLICIT = 0, 1
+IMPLICIT, EXPLICIT, IMPLICIT_GENERAL = 0, 1, 2
 P_VOL_MEAN, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_STD, P_COUNT = range(9)
 
 
@@ -27,7 +27,8 @@ class Config(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_keywords", C.c_int32), ("model", C.c_int32), ("max_days", C.c_int32),
                 ("loss_threshold", C.c_double),
                 ("drift_vol", C.c_float), ("drift_ctr", C.c_float), ("drift_cvr", C.c_float),
-                ("drift_on", C.c_int32), ("imp_thresh", C.c_float), ("auto_reset", C.c_int32), ("threads", C.c_int32)]
+                ("drift_on", C.c_int32), ("imp_thresh", C.c_float), ("auto_reset", C.c_int32), ("threads", C.c_int32),
+                ("max_bidders", C.c_int32), ("participation_rate", C.c_float), ("num_winners", C.c_int32)]
 
 
 class Tape(C.Structure):
@@ -140,10 +141,12 @@ class OracleEngine:
     """Holds the caller-owned state arrays of orc_step for N envs x K keywords."""
 
     def __init__(self, num_envs, num_keywords, model=IMPLICIT, max_days=60, loss_threshold=10000.0,
-                 drift=(0.03, 0.03, 0.03), drift_on=False, imp_thresh=0.05, auto_reset=False, threads=1):
+                 drift=(0.03, 0.03, 0.03), drift_on=False, imp_thresh=0.05, auto_reset=False, threads=1,
+                 max_bidders=30, participation_rate=0.6, num_winners=1):
         self.N, self.K = int(num_envs), int(num_keywords)
         self.cfg = Config(self.N, self.K, model, max_days, loss_threshold, drift[0], drift[1], drift[2],
-                          1 if drift_on else 0, imp_thresh, 1 if auto_reset else 0, threads)
+                          1 if drift_on else 0, imp_thresh, 1 if auto_reset else 0, threads,
+                          int(max_bidders), float(participation_rate), int(num_winners))
         N, K = self.N, self.K
         self.params = np.zeros((P_COUNT, N, K), dtype=np.float32)
         self.key = np.zeros(N, dtype=np.uint64)

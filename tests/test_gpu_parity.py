@@ -166,6 +166,58 @@ def test_g3_explicit_replay_on_gpu(amd, golden):
         e.close()
 
 
+def test_g12_general_implicit_replay_on_gpu(amd, golden):
+    """G12: the reference's default ImplicitKeyword (Binomial bidders per call, raw Laplace bids, literal top-(w+n) clearing)
+    replayed through k_step_exact<IMPLICIT_GENERAL, TAPE>: integers exact, float64 cost sums bit-identical, cursors at the ends"""
+    for t in golden("g12_implicit_general_replay.json")["traces"]:
+        K = t["K"]
+        e = amd.StepEngine(1, K, model=2, seed=1)
+        e.set_general_model(t["max_bidders"], t["participation_rate"], 1)
+        kp = t["keyword_params"]
+        planes = np.zeros((8, 1, K), np.float32)
+        for i, name in ((2, "bid_loc"), (3, "bid_scale"), (4, "bctr"), (5, "sctr"), (6, "rev_mean"), (7, "rev_std")):
+            planes[i, 0] = [p[name] for p in kp]
+        e.set_all_params(planes)
+        e.reset()
+        tp = t["tape"]
+        tape = amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"],
+                              x_impressions=tp["bidders"], x_cost=tp["bids"])
+        out = e.step_replay(np.array(t["bids"], np.float32), t["budget"], tape)
+        ref = t["out"]
+        assert out["impressions"][0].tolist() == ref["impressions"]
+        assert out["buyside_clicks"][0].tolist() == ref["buyside_clicks"]
+        assert out["sellside_conversions"][0].tolist() == ref["sellside_conversions"]
+        assert np.array_equal(out["cost"][0], np.array(ref["cost"]).astype(np.float32))     # f64 sum in reference order
+        np.testing.assert_allclose(out["reward"][0], sum(ref["profit"]), rtol=0, atol=1e-9)
+        assert tape.end["ximp"][0] == len(tp["bidders"]) and tape.end["xcost"][0] == len(tp["bids"])
+        assert tape.end["click"][0] == len(tp["click"]) and tape.end["conv"][0] == len(tp["conv"]) and tape.end["rev"][0] == len(tp["rev"])
+        e.close()
+
+
+@pytest.mark.parametrize("budget,winners,pool", [(1e9, 1, (30, 0.6)), (3.0, 1, (30, 0.6)), (1e9, 2, (30, 0.6)), (1e9, 1, (3, 0.4)), (2.0, 2, (70, 0.5))])
+def test_general_implicit_matches_oracle(amd, budget, winners, pool):
+    """the engine's own stream for the default ImplicitKeyword model == the C oracle, bit for bit (incl. a binding budget,
+    two winning placements, pools smaller than w + n - zero padding - and larger than a wavefront), with drift"""
+    N, K = 3, 20
+    rng = np.random.default_rng(8)
+    planes = np.stack([rng.integers(0, 90, (N, K)), rng.random((N, K)) * 6, rng.uniform(0.0, 0.3, (N, K)), rng.uniform(0.05, 0.15, (N, K)),
+                       rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.3, 1.5, (N, K)),
+                       rng.uniform(0.02, 0.3, (N, K))]).astype(np.float32)
+    e = amd.StepEngine(N, K, model=2, seed=13, drift_enabled=True)
+    e.set_general_model(pool[0], pool[1], winners)
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes, drift_on=True, max_bidders=pool[0], participation_rate=pool[1], num_winners=winners)
+    for _ in range(3):
+        bids = o.sample_bids(0.05, 0.5)
+        got, ref = e.step(bids, budget), o.step(bids, budget)
+        H.assert_step_equal(got, ref, implicit=False)
+    assert got["impressions"].sum() > 0
+    o.materialize_drift()
+    assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+
+
 def test_g8_env_episodes_on_gpu(amd, golden):
     for ep in golden("g8_env_episodes.json")["episodes"]:
         K = ep["K"]

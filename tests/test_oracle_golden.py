@@ -123,6 +123,74 @@ def test_g3_explicit_replay(golden):
     assert any(c > i for t in g["traces"] for c, i in zip(t["out"]["buyside_clicks"], t["out"]["impressions"]))
 
 
+# ---------------------------------------------------------------- G12: the reference's default ImplicitKeyword
+def test_g12_general_implicit_replay(golden):
+    """the non-env ImplicitKeyword (B ~ Binomial bidders per call, raw Laplace bids, literal top-(w+n) second-price clearing:
+    synthetic_kw_classes.py:610-686, synthetic_kw_helpers.py:116-180) in the reference's campaign loop, replayed from the
+    variates the reference drew: integers exact, float64 cost sums bit-exact (same operation order), cursors at the tape ends"""
+    g = golden("g12_implicit_general_replay.json")
+    for t in g["traces"]:
+        K = t["K"]
+        eng = orc.OracleEngine(1, K, model=orc.IMPLICIT_GENERAL, max_bidders=t["max_bidders"], participation_rate=t["participation_rate"])
+        kp = t["keyword_params"]
+        eng.params[2, 0] = [p["bid_loc"] for p in kp]
+        eng.params[3, 0] = [p["bid_scale"] for p in kp]
+        eng.params[4, 0] = [p["bctr"] for p in kp]
+        eng.params[5, 0] = [p["sctr"] for p in kp]
+        eng.params[6, 0] = [p["rev_mean"] for p in kp]
+        eng.params[7, 0] = [p["rev_std"] for p in kp]
+        tp = t["tape"]
+        tape = orc.TapeSource(click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"], x_impressions=tp["bidders"], x_cost=tp["bids"])
+        tape.set_volumes(np.array(t["volumes"]).reshape(1, K))
+        o = eng.step(np.array(t["bids"], dtype=np.float32), t["budget"], tape)
+        ref = t["out"]
+        assert o["impressions"][0].tolist() == ref["impressions"]
+        assert o["clicks"][0].tolist() == ref["buyside_clicks"]
+        assert o["conversions"][0].tolist() == ref["sellside_conversions"]
+        assert o["cost"][0].tolist() == ref["cost"]                       # same f64 operation order: bit-exact
+        np.testing.assert_allclose(o["revenue"][0], ref["revenue"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o["reward"][0], sum(ref["profit"]), rtol=0, atol=1e-9)
+        cur = tape.cursors()
+        assert cur["ximp"] == len(tp["bidders"]) and cur["xcost"] == len(tp["bids"])
+        assert cur["click"] == len(tp["click"]) and cur["conv"] == len(tp["conv"]) and cur["rev"] == len(tp["rev"])
+    assert any(min(t["tape"]["bidders"]) < 3 for t in g["traces"])       # the zero-padding case (fewer bidders than w+n) occurs
+    assert any(t["budget"] < 1e8 and sum(t["out"]["buyside_clicks"]) > 0 for t in g["traces"])
+
+
+def test_general_implicit_stream_law():
+    """the engine's own stream for that model: bidders per call ~ Binomial(30, 0.6), the winning price is the highest raw
+    Laplace(0, 0.1) competitor bid - checked on the win rate and the mean price at a given bid against a numpy simulation of
+    the reference's samplers (rng.binomial, rng.laplace; synthetic_kw_classes.py:659-665, 681-686)"""
+    N, K, V = 64, 8, 240
+    eng = orc.OracleEngine(N, K, model=orc.IMPLICIT_GENERAL, threads=4)
+    eng.params[0] = V
+    eng.params[1] = 0.0
+    eng.params[2] = 0.0
+    eng.params[3] = 0.1
+    eng.params[4] = 1.0            # every impression clicked
+    eng.params[5] = 0.0
+    eng.params[6] = 1.0
+    eng.params[7] = 0.1
+    eng.key[:] = np.arange(1, N + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    bid = 0.30
+    o = eng.step(np.full((N, K), bid, np.float32), 1e9)
+    n = N * K * V
+    win_rate = o["impressions"].sum() / n
+    price = o["cost"].sum() / max(o["clicks"].sum(), 1)
+    rng = np.random.default_rng(7)
+    wins, costs = 0, 0.0
+    for _ in range(2000):                      # 2000 calls of 24 x 10 auctions, B drawn per call as the reference does
+        B = rng.binomial(30, 0.6)
+        m = rng.laplace(0.0, 0.1, (B, 240)).max(axis=0) if B > 0 else np.zeros(240)
+        if B < 3:
+            m = np.maximum(m, 0.0)
+        w = bid > m
+        wins += int(w.sum())
+        costs += float(m[w].sum())
+    ref_rate, ref_price = wins / (2000 * 240), costs / max(wins, 1)
+    assert abs(win_rate - ref_rate) < 0.01 and abs(price - ref_price) < 0.004
+
+
 # ---------------------------------------------------------------- G4 drift (f64 restatement)
 def test_g4_update_keywords(golden):
     for s in golden("g4_update_keywords.json")["sequences"]:
