@@ -29,7 +29,8 @@ class Config(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("impressions", "buyside_clicks", "sellside_conversions", "cost", "revenue",
-                                          "reward", "cumulative_profit", "days_passed", "terminated", "truncated")]
+                                          "reward", "cumulative_profit", "days_passed", "terminated", "truncated",
+                                          "counts_u16", "counts_overflow")]
 
 
 class Quantiles(C.Structure):
@@ -103,7 +104,11 @@ def lib():
         "adc_engine_set_episode_state": ([vp, vp, vp], C.c_int),
         "adc_engine_step": ([vp, vp, vp, C.POINTER(StepOut)], C.c_int),
         "adc_engine_step_device": ([vp, vp, vp], C.c_int),
+        "adc_engine_step_async": ([vp, vp, vp, C.POINTER(StepOut)], C.c_int),
+        "adc_engine_step_flat_async": ([vp, vp, vp, vp, vp, vp], C.c_int),
+        "adc_engine_wait": ([vp], C.c_int),
         "adc_engine_fetch": ([vp, C.POINTER(StepOut)], C.c_int),
+        "adc_engine_out_offsets": ([vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], C.c_int),
         "adc_engine_synchronize": ([vp], C.c_int),
         "adc_engine_step_flat": ([vp, vp, vp, vp, vp, vp], C.c_int),
         "adc_engine_step_replay": ([vp, vp, vp, C.POINTER(Tape), C.POINTER(StepOut)], C.c_int),
@@ -144,7 +149,7 @@ def lib():
         fn = getattr(L, name)      # AttributeError here = the .so does not export what the header declares
         fn.argtypes = args
         fn.restype = res
-    if L.adc_abi_version() != 2:
+    if L.adc_abi_version() != 3:
         raise EngineError("libadcraft_hip.so ABI version mismatch")
     _lib = L
     return L

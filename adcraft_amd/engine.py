@@ -19,10 +19,64 @@ _OUT_SPEC = (("impressions", np.int32, True), ("buyside_clicks", np.int32, True)
              ("terminated", np.uint8, False), ("truncated", np.uint8, False))
 
 
+_COUNT_NAMES = ("impressions", "buyside_clicks", "sellside_conversions")
+
+
+def _out_offsets(lib, handle):
+    off, total = (C.c_size_t * 10)(), C.c_size_t()
+    check(lib.adc_engine_out_offsets(handle, off, C.byref(total)))
+    return list(off), total.value
+
+
+def _views_at(block, offsets, N, K, names):
+    """numpy views of a byte block at the engine's output offsets"""
+    out = {}
+    for (name, dt, per_kw), off in zip(_OUT_SPEC, offsets):
+        if name in names:
+            count = N * K if per_kw else N
+            out[name] = block[off:off + count * np.dtype(dt).itemsize].view(dt).reshape((N, K) if per_kw else (N,))
+    return out
+
+
+def _alloc_outputs(alloc, N, K, compact, offsets, block_bytes):
+    """the step outputs of one engine as views of ONE page-locked block laid out like the engine's device block, so that they
+    come back in one transfer (adc_engine_out_offsets).  With compact counts the three count arrays are uint16 views [N, K] of
+    a [N, 3, K] array the device packs (adc_step_out.counts_u16) and no int32 counts are transferred."""
+    names = [n for n, _, _ in _OUT_SPEC if not (compact and n in _COUNT_NAMES)]
+    out = _views_at(alloc((block_bytes,), np.uint8), offsets, N, K, names)
+    if not compact:
+        return out, None, None
+    packed, overflow = alloc((N, 3, K), np.uint16), alloc((1,), np.int32)
+    for i, name in enumerate(_COUNT_NAMES):
+        out[name] = packed[:, i, :]
+    return out, packed, overflow
+
+
+def _out_struct(out, packed, overflow, b0, b1, small=None):
+    """adc_step_out over rows b0:b1 of the output arrays (small: this part's own per-env arrays)"""
+    src = lambda name, per_kw: (out[name][b0:b1] if per_kw or small is None else small[name]).ctypes.data   # noqa: E731
+    if packed is None:
+        return _ffi.StepOut(*(src(name, per_kw) for name, _, per_kw in _OUT_SPEC), None, None)
+    ptrs = [None if name in _COUNT_NAMES else src(name, per_kw) for name, _, per_kw in _OUT_SPEC]
+    return _ffi.StepOut(*ptrs, packed[b0:b1].ctypes.data, overflow[b0:b0 + 1].ctypes.data if overflow.size > 1 else overflow.ctypes.data)
+
+
+def _is_buffer(a, buf):
+    """a is the page-locked array buf itself (or a full view of it): nothing to stage"""
+    return isinstance(a, np.ndarray) and a.dtype == buf.dtype and a.size == buf.size and a.flags.c_contiguous \
+        and a.__array_interface__["data"][0] == buf.__array_interface__["data"][0]
+
+
+def _check_overflow(overflow):
+    if overflow is not None and overflow.any():
+        overflow[...] = 0
+        raise OverflowError("a keyword count exceeded 65535: construct the engine / env with compact_counts=False")
+
+
 class StepEngine:
     def __init__(self, num_envs, num_keywords, model=MODEL_IMPLICIT, *, device_id=0, max_days=60,
                  loss_threshold=10000.0, drift=(0.03, 0.03, 0.03), drift_enabled=False, impression_thresh=0.05,
-                 auto_reset=False, env_id_base=0, seed=0):
+                 auto_reset=False, env_id_base=0, seed=0, compact_counts=False):
         self._h = None
         self._lib = _ffi.lib()
         self.num_envs, self.num_keywords, self.model = int(num_envs), int(num_keywords), int(model)
@@ -37,8 +91,10 @@ class StepEngine:
         N, K = self.num_envs, self.num_keywords
         # step I/O buffers live in page-locked host memory: observations DMA straight into these numpy arrays
         self._pinned = []
-        self.out = {name: self._pinned_array((N, K) if per_kw else (N,), dt) for name, dt, per_kw in _OUT_SPEC}
-        self._out = _ffi.StepOut(*(self.out[name].ctypes.data for name, _, _ in _OUT_SPEC))
+        self.compact_counts = bool(compact_counts)
+        self.out, self._counts_u16, self._overflow = _alloc_outputs(self._pinned_array, N, K, self.compact_counts,
+                                                                    *_out_offsets(self._lib, self._h))
+        self._out = _out_struct(self.out, self._counts_u16, self._overflow, 0, N)
         self._flat_io = None
         self._bids_stage = self._pinned_array((N, K), np.float32)
         self._budget_stage = self._pinned_array((N,), np.float32)
@@ -59,6 +115,7 @@ class StepEngine:
             self._lib.adc_engine_destroy(self._h)
             self._h = None
             self.out, self._bids_stage, self._budget_stage, self._flat_io = {}, None, None, None      # drop views before freeing
+            self._counts_u16, self._overflow = None, None
             for p in self._pinned:
                 self._lib.adc_host_free(p)
             self._pinned = []
@@ -155,14 +212,21 @@ class StepEngine:
 
     # ---- the hot path
     def _actions(self, bids, budget):
-        self._bids_stage[...] = np.asarray(bids, dtype=np.float32).reshape(-1, self.num_keywords) if np.ndim(bids) else bids
-        self._budget_stage[...] = budget
+        if not _is_buffer(bids, self._bids_stage):
+            self._bids_stage[...] = np.asarray(bids, dtype=np.float32).reshape(-1, self.num_keywords) if np.ndim(bids) else bids
+        if not _is_buffer(budget, self._budget_stage):
+            self._budget_stage[...] = budget
+        return self._bids_stage, self._budget_stage
+
+    def action_buffers(self):
+        """(bids [N, K], budget [N]) page-locked arrays: fill them in place and pass them to step() to skip the staging copy"""
         return self._bids_stage, self._budget_stage
 
     def step(self, bids, budget, copy=True):
         """host in / host out, synchronous.  Returns dict of numpy arrays (views of reused buffers if copy=False)."""
         b, g = self._actions(bids, budget)
         check(self._lib.adc_engine_step(self._h, b.ctypes.data, g.ctypes.data, C.byref(self._out)))
+        _check_overflow(self._overflow)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
     def step_flat(self, flat_actions):
@@ -177,9 +241,21 @@ class StepEngine:
                                              self.out["terminated"].ctypes.data, self.out["truncated"].ctypes.data))
         return obs, self.out["reward"], self.out["terminated"], self.out["truncated"]
 
+    def step_async(self, bids_ptr, budget_ptr, out_struct=None):
+        """enqueue a host-in / host-out step and return (adc_engine_step_async); the buffers (page-locked) must stay
+        untouched until wait()"""
+        check(self._lib.adc_engine_step_async(self._h, bids_ptr, budget_ptr, C.byref(self._out if out_struct is None else out_struct)))
+
+    def step_flat_async(self, act_ptr, obs_ptr, reward_ptr, term_ptr, trunc_ptr):
+        check(self._lib.adc_engine_step_flat_async(self._h, act_ptr, obs_ptr, reward_ptr, term_ptr, trunc_ptr))
+
+    def wait(self):
+        check(self._lib.adc_engine_wait(self._h))
+
     def step_replay(self, bids, budget, tape, copy=True):
         b, g = self._actions(bids, budget)
         check(self._lib.adc_engine_step_replay(self._h, b.ctypes.data, g.ctypes.data, C.byref(tape.struct), C.byref(self._out)))
+        _check_overflow(self._overflow)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
     def step_device(self, d_bids=None, d_budget=None):
@@ -188,6 +264,7 @@ class StepEngine:
 
     def fetch(self, copy=True):
         check(self._lib.adc_engine_fetch(self._h, C.byref(self._out)))
+        _check_overflow(self._overflow)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
     def synchronize(self):
@@ -368,6 +445,141 @@ class StepEngine:
         check(self._lib.adc_engine_metrics_read_nk(self._h, pc.ctypes.data, None if si is None else si.ctypes.data,
                                                    None if sp is None else sp.ctypes.data))
         return pc / 100.0, si, sp
+
+
+class ShardedStepEngine:
+    """One vector of envs on ONE device, held by several engines (each with its own HIP stream) and stepped together.
+
+    A host-in / host-out step is PCIe-bound (4 B per keyword up, 20 B down, against a 0.2 ms kernel at 4096 x 256): with the
+    envs split over a few engines, enqueued asynchronously from page-locked buffers (adc_engine_step_async), one part's
+    transfers overlap another part's kernels.  Results are those of a single engine: random streams are keyed by the
+    GLOBAL env id (the multi-GPU sharding invariant).  The I/O arrays are single [N, K] page-locked arrays; every part reads
+    and writes its rows of them, so callers see the same buffers a StepEngine gives them."""
+
+    def __init__(self, num_envs, num_keywords, model=MODEL_IMPLICIT, *, shards=4, env_id_base=0, compact_counts=False, **kw):
+        self.num_envs, self.num_keywords, self.model = int(num_envs), int(num_keywords), int(model)
+        if np.ndim(shards):          # relative sizes: a small first part puts its results on the bus early
+            edges = np.concatenate([[0.0], np.cumsum(np.asarray(shards, dtype=np.float64))])
+            self.bounds = sorted(set(int(round(b)) for b in edges / edges[-1] * self.num_envs))
+        else:
+            shards = max(1, min(int(shards), self.num_envs))
+            self.bounds = [int(b) for b in np.linspace(0, self.num_envs, shards + 1)]
+        self.parts = [StepEngine(b1 - b0, num_keywords, model, env_id_base=env_id_base + b0, **kw)
+                      for b0, b1 in zip(self.bounds[:-1], self.bounds[1:])]
+        N, K = self.num_envs, self.num_keywords
+        alloc = self.parts[0]._pinned_array
+        self.compact_counts = bool(compact_counts)
+        # per-keyword outputs: planes of one [., N, K] page-locked array (a part's rows of all planes = one 2-D transfer);
+        # per-env outputs: every part has its own small block laid out like its device block (one transfer), gathered into
+        # the [N] arrays after the wait
+        per_kw = [n for n, _, k in _OUT_SPEC if k and not (self.compact_counts and n in _COUNT_NAMES)]
+        planes = alloc((len(per_kw), N, K), np.int32)
+        self.out = {n: planes[i].view(dict((a, b) for a, b, _ in _OUT_SPEC)[n]) for i, n in enumerate(per_kw)}
+        self._counts_u16, self._overflow = None, None
+        if self.compact_counts:
+            self._counts_u16, self._overflow = alloc((N, 3, K), np.uint16), alloc((len(self.parts),), np.int32)
+            for i, n in enumerate(_COUNT_NAMES):
+                self.out[n] = self._counts_u16[:, i, :]
+        per_env = [n for n, _, k in _OUT_SPEC if not k]
+        self.out.update({n: np.zeros(N, dt) for n, dt, k in _OUT_SPEC if not k})
+        self._small = []
+        for p in self.parts:
+            off, total = _out_offsets(p._lib, p._h)
+            self._small.append(_views_at(alloc((total - off[5],), np.uint8), [o - off[5] for o in off], p.num_envs, K, per_env))
+        self._bids_stage, self._budget_stage = alloc((N, K), np.float32), alloc((N,), np.float32)
+        self._flat_act, self._flat_obs = None, None
+        self._in_ptrs = [(self._bids_stage[b0:b1].ctypes.data, self._budget_stage[b0:b1].ctypes.data)
+                         for b0, b1 in zip(self.bounds[:-1], self.bounds[1:])]
+        self._outs = []
+        for i, (b0, b1) in enumerate(zip(self.bounds[:-1], self.bounds[1:])):
+            o = _out_struct(self.out, self._counts_u16, self._overflow, b0, b1, self._small[i])
+            if self._overflow is not None:
+                o.counts_overflow = self._overflow[i:i + 1].ctypes.data
+            self._outs.append(o)
+
+    def _each(self):
+        return zip(self.parts, self.bounds[:-1], self.bounds[1:])
+
+    def close(self):
+        self.out, self._bids_stage, self._budget_stage, self._flat_act, self._flat_obs = {}, None, None, None, None
+        self._counts_u16, self._overflow, self._small = None, None, []
+        for p in self.parts:
+            p.close()
+        self.parts = []
+
+    def set_all_params(self, planes):
+        for p, b0, b1 in self._each():
+            p.set_all_params(np.ascontiguousarray(planes[:, b0:b1]))
+
+    def get_all_params(self):
+        return np.concatenate([p.get_all_params() for p in self.parts], axis=1)
+
+    def reset(self, env_mask=None, seeds=None):
+        for p, b0, b1 in self._each():
+            p.reset(None if env_mask is None else np.asarray(env_mask)[b0:b1], None if seeds is None else np.asarray(seeds)[b0:b1])
+
+    def generate_keywords(self, table, no_vol_prob=0.0, env_mask=None, serial=0):
+        for p, b0, b1 in self._each():
+            p.generate_keywords(table, no_vol_prob, None if env_mask is None else np.asarray(env_mask)[b0:b1], serial)
+
+    def set_limits(self, max_days, loss_threshold):
+        for p in self.parts:
+            p.set_limits(max_days, loss_threshold)
+
+    def get_rng_state(self):
+        ks, ts = zip(*(p.get_rng_state() for p in self.parts))
+        return np.concatenate(ks), np.concatenate(ts)
+
+    def synchronize(self):
+        for p in self.parts:
+            p.synchronize()
+
+    def step(self, bids, budget, copy=True):
+        """host in / host out: every part's step is enqueued, then all are awaited"""
+        stage_bids = not _is_buffer(bids, self._bids_stage)      # action_buffers() filled in place: nothing to stage
+        if stage_bids and np.ndim(bids):
+            bids = np.asarray(bids, dtype=np.float32).reshape(-1, self.num_keywords)
+        if not _is_buffer(budget, self._budget_stage):
+            self._budget_stage[...] = budget
+        for (p, b0, b1), o, (pb, pg) in zip(self._each(), self._outs, self._in_ptrs):
+            if stage_bids:                              # part by part: the next part is staged while this one's transfer runs
+                self._bids_stage[b0:b1] = bids[b0:b1] if np.ndim(bids) else bids
+            p.step_async(pb, pg, o)
+        self._wait_and_gather()
+        _check_overflow(self._overflow)
+        return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+    def _wait_and_gather(self):
+        for p in self.parts:
+            p.wait()
+        for small, b0, b1 in zip(self._small, self.bounds[:-1], self.bounds[1:]):
+            for name, a in small.items():
+                self.out[name][b0:b1] = a
+
+    def action_buffers(self):
+        """(bids [N, K], budget [N]) page-locked arrays: fill them in place and pass them to step() to skip the staging copy"""
+        return self._bids_stage, self._budget_stage
+
+    def step_flat(self, flat_actions):
+        N, K = self.num_envs, self.num_keywords
+        if self._flat_act is None:
+            alloc = self.parts[0]._pinned_array
+            self._flat_act, self._flat_obs = alloc((N, K + 1), np.float32), alloc((N, 5 * K + 2), np.float32)
+        o = self.out
+        flat_actions = np.asarray(flat_actions, dtype=np.float32).reshape(N, K + 1)
+        for (p, b0, b1), small in zip(self._each(), self._small):
+            if not _is_buffer(flat_actions, self._flat_act):
+                self._flat_act[b0:b1] = flat_actions[b0:b1]
+            p.step_flat_async(self._flat_act[b0:b1].ctypes.data, self._flat_obs[b0:b1].ctypes.data, small["reward"].ctypes.data,
+                              small["terminated"].ctypes.data, small["truncated"].ctypes.data)
+        self._wait_and_gather()
+        return self._flat_obs, o["reward"], o["terminated"], o["truncated"]
+
+    def step_device(self, d_bids=None, d_budget=None):
+        if d_bids is not None or d_budget is not None:
+            raise NotImplementedError("caller-owned device actions need one engine (engine_shards=1)")
+        for p in self.parts:
+            p.step_device()
 
 
 class ReplayTape:

@@ -171,6 +171,35 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
 
 
 # ---------------------------------------------------------------------------------------------------------------- rank / launcher
+def host_step(local_rank, steps=120):
+    """what a numpy policy sees: BiddingSimulationVectorEnv.step at 4096 x 256, actions from host arrays, observations into
+    host arrays (the reference's gymnasium call, SURVEY 8 row b).  PCIe-bound: 4 B per keyword up, 20 B down
+    (14 B with uint16 counts)."""
+    from adcraft_amd import gymnasium_kw_utils as utils
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    N, K = 4096, 256
+    act = {"keyword_bids": np.full((N, K), 0.8, np.float32), "budget": np.full(N, 1e6, np.float32)}
+    res = {}
+    for key, opts in (("ms", {}), ("ms_u16_counts", {"compact_counts": True})):
+        vec = BiddingSimulationVectorEnv(N, keyword_config=utils.experiment_keyword_config(128, 0.8), num_keywords=K, budget=1e6,
+                                         param_sampler="device", device_id=local_rank, loss_threshold=1e12, **opts)   # 60-day episodes, autoreset
+        vec.reset(seed=1)
+        for _ in range(5):
+            vec.step(act)
+        per_step = np.empty(steps)
+        for i in range(steps):
+            t0 = time.perf_counter()
+            vec.step(act)
+            per_step[i] = time.perf_counter() - t0
+        res[key] = round(float(np.median(per_step)) * 1e3, 4)
+        res[key + "_mean_incl_episode_ends"] = round(float(per_step.mean()) * 1e3, 4)   # every 60th step copies the final observations out
+        vec.close()
+    res["value"] = round(N * K / (res["ms"] * 1e-3), 1)
+    res.update(unit="keyword-steps/s", workload="cfg2 through BiddingSimulationVectorEnv.step (dict actions in, dict observations out)",
+               engines_on_device=4, steps=steps)
+    return res
+
+
 def rehearse_rank(args, rank, world):
     """--rehearse: everything around the GPU work, without a GPU (tests/test_distributed_cpu.py): the id hand-over, a
     reduction, the slowest-rank time, the line"""
@@ -228,6 +257,8 @@ def run_rank(args):
                 line[k] = main[k]
         if also:
             line["also"] = also
+        if world == 1 and not args.no_also and not args.config:
+            line["host_step"] = host_step(local_rank)
         print(json.dumps(line), flush=True)
 
 

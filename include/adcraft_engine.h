@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADC_ABI_VERSION 2
+#define ADC_ABI_VERSION 3
 
 typedef enum adc_status {
     ADC_OK = 0,
@@ -100,6 +100,12 @@ typedef struct adc_step_out {
     int32_t *days_passed;      /* [N]   after the step, :227,243 */
     uint8_t *terminated;       /* [N]   :228 */
     uint8_t *truncated;        /* [N]   :225 */
+    /* optional compact form of the three counts: uint16 [N][3][K] = per env: impressions | buyside_clicks |
+     * sellside_conversions (K even), packed on the device: 6 B instead of 12 B per keyword over PCIe (a host step of
+     * 4096 x 256 is PCIe-bound).  A count above 65535 is stored as 65535 and *counts_overflow (nullable) is set to 1:
+     * use the int32 pointers then. */
+    uint16_t *counts_u16;
+    int32_t *counts_overflow;
 } adc_step_out;
 
 /* device-resident buffers of the engine (for zero-copy consumers: torch / DLPack / RL on GPU) */
@@ -201,6 +207,10 @@ int adc_engine_step(adc_engine *e, const float *bids_nk, const float *budget_n, 
 int adc_engine_step_device(adc_engine *e, const float *d_bids_nk, const float *d_budget_n);
 /* copy the last step's outputs to host buffers (synchronises) */
 int adc_engine_fetch(adc_engine *e, adc_step_out *out);
+/* Byte offsets of the ten adc_step_out arrays (in the struct's order) inside the engine's device output block, and the
+ * block's size.  Host buffers placed at these offsets of one allocation are filled by ONE transfer; equal-sized outputs at
+ * a constant host stride (e.g. planes of one [5][N][K] array) by one 2-D transfer; anything else by one transfer each. */
+int adc_engine_out_offsets(const adc_engine *e, size_t offsets[10], size_t *block_bytes);
 int adc_engine_synchronize(adc_engine *e);
 /* the same step with FlatArrayWrapper-layout host I/O (adcraft/wrappers/flat_array.py:44-87), synchronous:
  * flat_actions [N][K+1] = [budget, bids...] in; flat_obs [N][5K+2] (sorted-key order, see
@@ -208,6 +218,13 @@ int adc_engine_synchronize(adc_engine *e);
  * happens on the device, so the host moves one array each way. */
 int adc_engine_step_flat(adc_engine *e, const float *flat_actions, float *flat_obs, double *reward, uint8_t *terminated,
                          uint8_t *truncated);
+/* the asynchronous forms: enqueue (actions up, kernels, outputs down) on the engine's stream and return; adc_engine_wait
+ * completes them.  Give them page-locked buffers (adc_host_alloc) and the transfers of one engine overlap the kernels of
+ * another on the same device: a vector env split over a few engines hides most of its PCIe time that way. */
+int adc_engine_step_async(adc_engine *e, const float *bids_nk, const float *budget_n, adc_step_out *out);
+int adc_engine_step_flat_async(adc_engine *e, const float *flat_actions_n_k1, float *flat_obs_n_5k2, double *reward_n,
+                               uint8_t *terminated_n, uint8_t *truncated_n);
+int adc_engine_wait(adc_engine *e);
 /* replay a recorded tape instead of the engine's own random stream (parity mode) */
 int adc_engine_step_replay(adc_engine *e, const float *bids_nk, const float *budget_n, const adc_tape *tape,
                            adc_step_out *out);

@@ -22,3 +22,18 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _resource_trace(request):
+    """ADCRAFT_TEST_TRACE=<file>: one line per test with the process's open descriptors and resident memory after it -
+    what leaked engines (streams, page-locked buffers) show up in first"""
+    yield
+    path = os.environ.get("ADCRAFT_TEST_TRACE")
+    if path:
+        with open("/proc/self/statm") as f:
+            rss_mb = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") >> 20
+        with open(path, "a") as f:
+            with open("/proc/self/maps") as m:
+                libs = sorted({line.split()[-1] for line in m if ".so" in line and ("torch/lib" in line or "rccl" in line or "hsa-runtime" in line)})
+            f.write(f"{request.node.nodeid} fds={len(os.listdir('/proc/self/fd'))} rss_mb={rss_mb} torch={'torch' in sys.modules} {libs}\n")

@@ -259,3 +259,72 @@ def test_vector_env_device_sampler(pkg):
     vec.reset(seed=9)
     assert np.array_equal(vec.engine.get_all_params(), p1)          # same seed, same keyword sets
     vec.close()
+
+
+def test_vector_env_split_over_several_engines_gives_the_same_steps(pkg):
+    """engine_shards: the envs held by several engines on the device and stepped together (asynchronous host steps from
+    page-locked buffers, transfers overlapping kernels) - observation for observation what one engine returns"""
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    N, K = 10, 24
+    rng = np.random.default_rng(3)
+    outs = []
+    for shards, flat in [(1, False), (3, False), (1, True), (4, True)]:
+        vec = BiddingSimulationVectorEnv(N, keyword_config=_cfg(48, 0.6), num_keywords=K, max_days=3, engine_shards=shards, flat=flat,
+                                         param_sampler="vectorised")
+        vec.reset(seed=11)
+        rng = np.random.default_rng(3)
+        traj = []
+        for _ in range(5):                                    # crosses an episode end (autoreset) at day 3
+            bids = np.round(rng.uniform(0.3, 1.0, (N, K)), 2).astype(np.float32)
+            act = np.concatenate([np.full((N, 1), 40.0, np.float32), bids], axis=1) if flat else {"keyword_bids": bids, "budget": np.full(N, 40.0, np.float32)}
+            obs, rew, term, trunc, infos = vec.step(act)
+            traj.append((obs.copy() if flat else {k: v.copy() for k, v in obs.items()}, rew.copy(), term.copy(), trunc.copy()))
+        outs.append(traj)
+        vec.close()
+    for a, b in ((outs[0], outs[1]), (outs[2], outs[3])):
+        for (oa, ra, ta, ua), (ob, rb, tb, ub) in zip(a, b):
+            if isinstance(oa, dict):
+                assert all(np.array_equal(oa[k], ob[k]) for k in oa)
+            else:
+                assert np.array_equal(oa, ob)
+            assert np.array_equal(ra, rb) and np.array_equal(ta, tb) and np.array_equal(ua, ub)
+    assert outs[0][2][2].all() and outs[0][0][0]["impressions"].sum() > 0
+
+
+def test_compact_counts_are_the_same_counts_as_uint16(pkg):
+    """compact_counts: the three count observations packed to uint16 on the device (adc_step_out.counts_u16) - the same
+    numbers, and a count beyond 65535 raises instead of being clipped silently"""
+    from adcraft_amd.engine import MODEL_IMPLICIT, P_VOL_MEAN, StepEngine
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    N, K = 10, 24
+    trajs = []
+    for compact, shards in [(False, 1), (True, 1), (True, 3)]:
+        vec = BiddingSimulationVectorEnv(N, keyword_config=_cfg(48, 0.6), num_keywords=K, max_days=3, engine_shards=shards,
+                                         compact_counts=compact, param_sampler="vectorised")
+        vec.reset(seed=5)
+        rng = np.random.default_rng(8)
+        traj = []
+        for _ in range(4):
+            bids = np.round(rng.uniform(0.3, 1.0, (N, K)), 2).astype(np.float32)
+            act = {"keyword_bids": bids, "budget": np.full(N, 40.0, np.float32)}
+            if shards == 3:                         # actions written in place into the engine's page-locked buffers
+                buf = vec.action_buffers()
+                buf["keyword_bids"][...], buf["budget"][...] = act["keyword_bids"], act["budget"]
+                act = buf
+            obs, rew, term, trunc, _ = vec.step(act)
+            traj.append(({k: np.array(v) for k, v in obs.items()}, rew.copy()))
+        trajs.append(traj)
+        vec.close()
+    assert trajs[1][0][0]["impressions"].dtype == np.uint16 and trajs[0][0][0]["impressions"].sum() > 0
+    for other in trajs[1:]:
+        for (oa, ra), (ob, rb) in zip(trajs[0], other):
+            assert all(np.array_equal(oa[k], ob[k]) for k in oa) and np.array_equal(ra, rb)
+    eng = StepEngine(2, 4, MODEL_IMPLICIT, compact_counts=True, seed=1)
+    planes = np.zeros((8, 2, 4), np.float32)
+    planes[P_VOL_MEAN] = 70000.0
+    planes[2], planes[3], planes[4], planes[5], planes[6] = 0.0, 0.1, 0.5, 0.5, 1.0
+    eng.set_all_params(planes)
+    eng.reset()
+    with pytest.raises(OverflowError):
+        eng.step(np.full((2, 4), 5.0, np.float32), np.full(2, 1e9, np.float32))
+    eng.close()
