@@ -499,6 +499,21 @@ ADC_HD WinIntervals win_intervals(int32_t bid_c, float loc, float scale, uint64_
     return r;
 }
 
+// the clicked-win interval alone, for a bid: win_intervals(bid_c, ...).c_lo / .c_w.  With bid_c = min(bid, R + 1) these are the
+// words whose clicked win costs at most R cents (a win pays the competitor's cents, and wins iff they are below the bid)
+ADC_HD void clicked_win_interval(int32_t bid_c, float loc, float scale, uint64_t t_click, const AuctionLaw &law, const LogTableEntry *tab,
+                                 uint32_t &lo, uint32_t &width)
+{
+    lo = 0u;
+    width = 0u;
+    const uint32_t w_lo = lower_bound_v(1 - bid_c, loc, scale, tab), w_hi = lower_bound_v(bid_c, loc, scale, tab);
+    if (!(w_lo < w_hi)) return;
+    const uint64_t a = offset_reaching(w_lo, law.m_click, t_click);
+    uint64_t b = offset_reaching(w_hi, law.m_click, t_click);
+    b = b < 0xFFFFFFFFull ? b : 0xFFFFFFFFull;
+    if (a < b) { lo = (uint32_t)a; width = (uint32_t)(b - a); }
+}
+
 // revenue of a conversion in cents, round2(max(N(mu, sd), 0.01)) (adcraft/synthetic_kw_helpers.py:66-70), IMPLICIT path
 ADC_HD int32_t revenue_cents_tab(uint32_t w, float mu, float sd, const NormTableEntry *tab)
 {
