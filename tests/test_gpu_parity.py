@@ -120,6 +120,44 @@ def test_explicit_matches_oracle(amd, budget):
     _run_vs_oracle(amd, N, K, planes, steps=3, budget=budget, model=1, bid_lo=0.05, bid_hi=2.0)
 
 
+@pytest.mark.parametrize("case", ["full_width", "pool_exhausted", "huge_cells", "no_budget", "narrow", "drift_with_hint"])
+def test_explicit_day_kernel_and_its_fallbacks(amd, case):
+    """k_step_explicit_day (K <= 256: lane = keyword, one row of click lists in LDS) against the oracle, and every way out
+    of it: the shared overflow pool exhausted (-> k_step_explicit_rows), cells of more than 255 auctions (-> the serial
+    walker), a day that starts without budget; plus the scheduling hint that skips the fast pass on the following days
+    (drift then has to be applied by the day kernel)"""
+    steps, drift, budget = 4, False, 40.0
+    if case == "full_width":
+        N, K = 5, 256
+        planes = H.explicit_params(N, K, seed=31)
+    elif case == "pool_exhausted":            # 23 auctions, all in the day's first cell, nearly all shown and clicked: ~5000 per row
+        N, K = 2, 256
+        planes = H.explicit_params(N, K, seed=32)
+        planes[0], planes[1], planes[4] = 23.0, 0.0, 0.97
+        planes[2], planes[3] = 0.0, 25.0                                    # steep sigmoid at 0: every bid shows
+        budget = 1500.0
+    elif case == "huge_cells":
+        N, K = 2, 6
+        planes = H.explicit_params(N, K, seed=33)
+        planes[0], planes[1] = 9000.0, 100.0
+        budget, steps = 900.0, 2
+    elif case == "no_budget":
+        N, K = 3, 40
+        planes = H.explicit_params(N, K, seed=34)
+        budget = 0.0
+    elif case == "narrow":
+        N, K = 6, 7
+        planes = H.explicit_params(N, K, seed=35)
+        budget = 3.0
+    else:
+        N, K = 4, 96
+        planes = H.explicit_params(N, K, seed=36)
+        steps, drift, budget = 6, True, 25.0
+    n_bound = _run_vs_oracle(amd, N, K, planes, steps=steps, budget=budget, model=1, drift=drift, check_params=drift, bid_lo=0.05, bid_hi=2.0)
+    if case != "no_budget":
+        assert n_bound >= 0
+
+
 def test_explicit_drift(amd):
     planes = H.explicit_params(2, 10, seed=16)
     _run_vs_oracle(amd, 2, 10, planes, steps=3, budget=1000.0, model=1, drift=True, check_params=True)
