@@ -1,5 +1,5 @@
-"""-m gpu: the device-resident side of the ABI - external device pointers for actions (torch tensors, used
-here only as a device allocator), flat actions / flat observations emitted on the device, zero-copy reads."""
+"""-m gpu: the device-resident side of the ABI - external device pointers for actions (the test's own hipMalloc'ed buffers,
+tests/hip_ctypes.py), flat actions / flat observations emitted on the device, zero-copy reads."""
 import numpy as np
 import pytest
 
@@ -8,27 +8,8 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    return torch
-
-
-def _view(torch, ptr, nbytes, dtype, shape):
-    """zero-copy torch view of an engine buffer via __cuda_array_interface__"""
-    class _Buf:
-        pass
-    b = _Buf()
-    np_dt = np.dtype(dtype)
-    b.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": np_dt.str, "data": (ptr, False), "version": 2}
-    assert int(np.prod(shape)) * np_dt.itemsize == nbytes
-    return torch.as_tensor(b, device="cuda")
-
-
-def test_step_with_external_device_actions_and_flat_io(torch_cuda):
-    torch = torch_cuda
+def test_step_with_external_device_actions_and_flat_io():
+    from tests.hip_ctypes import DeviceArray, read_device
     from adcraft_amd import _ffi, gymnasium_kw_utils as utils
     from adcraft_amd.engine import StepEngine
     N, K = 64, 96
@@ -47,15 +28,14 @@ def test_step_with_external_device_actions_and_flat_io(torch_cuda):
     e.set_all_params(planes)
     e.reset()
     e.flat_obs_enable(True)
-    d_bids, d_budget = torch.from_numpy(bids).cuda(), torch.from_numpy(budget).cuda()
-    torch.cuda.synchronize()
-    e.step_device(d_bids.data_ptr(), d_budget.data_ptr())
+    d_bids, d_budget = DeviceArray(bids), DeviceArray(budget)
+    e.step_device(d_bids.ptr, d_budget.ptr)
     got = e.fetch()
     for k in want:
         assert np.array_equal(got[k], want[k]), k
     # flat observations written on the device == FlatArrayWrapper order of the dict observation
     p, nbytes = e.device_buffer(_ffi.BUF_FLAT_OBS)
-    flat = _view(torch, p, nbytes, np.float32, (N, 5 * K + 2)).cpu().numpy()
+    flat = read_device(p, nbytes, np.float32, (N, 5 * K + 2))
     for i in (0, N - 1):
         obs = dict(impressions=got["impressions"][i], buyside_clicks=got["buyside_clicks"][i], cost=got["cost"][i],
                    sellside_conversions=got["sellside_conversions"][i], revenue=got["revenue"][i],
@@ -63,16 +43,17 @@ def test_step_with_external_device_actions_and_flat_io(torch_cuda):
         assert np.array_equal(flat[i], utils.flatten_dict_array(obs).astype(np.float32))
     # zero-copy read of an output buffer
     p, nbytes = e.device_buffer(_ffi.BUF_IMPRESSIONS)
-    assert np.array_equal(_view(torch, p, nbytes, np.int32, (N, K)).cpu().numpy(), got["impressions"])
+    assert np.array_equal(read_device(p, nbytes, np.int32, (N, K)), got["impressions"])
     e.close()
+    d_bids.free()
+    d_budget.free()
 
     # (2) flat device actions [budget, bids...] -> same step
     e = StepEngine(N, K, seed=11)
     e.set_all_params(planes)
     e.reset()
-    flat_act = torch.from_numpy(np.concatenate([budget[:, None], bids], axis=1)).cuda()
-    torch.cuda.synchronize()
-    e.set_flat_actions_device(flat_act.data_ptr())
+    flat_act = DeviceArray(np.concatenate([budget[:, None], bids], axis=1))
+    e.set_flat_actions_device(flat_act.ptr)
     e.step_device()
     got2 = e.fetch()
     for k in want:
@@ -80,6 +61,7 @@ def test_step_with_external_device_actions_and_flat_io(torch_cuda):
     with pytest.raises(AssertionError):
         e.device_buffer(_ffi.BUF_FLAT_OBS)          # not enabled on this engine
     e.close()
+    flat_act.free()
 
 
 def test_bad_arguments_raise():
@@ -104,7 +86,7 @@ def test_bad_arguments_raise():
     assert _ffi.lib().adc_last_error() is not None
 
 
-def test_engine_checkpoint_resume(torch_cuda):
+def test_engine_checkpoint_resume():
     """state = params + rng state + episode state: a restored engine continues bit-identically"""
     from adcraft_amd.engine import StepEngine
     N, K = 8, 40
