@@ -258,6 +258,31 @@ def test_general_implicit_matches_oracle(amd, budget, winners, pool):
     e.close()
 
 
+@pytest.mark.parametrize("case", ["no_budget", "huge_cells", "full_width"])
+def test_general_implicit_day_kernel_and_its_fallbacks(amd, case):
+    """the default ImplicitKeyword under a binding budget: k_step_float_day<IMPLICIT_GENERAL> at full width, and its ways out
+    to the reference-order walker (a day that starts without budget; cells of more than 255 auctions)"""
+    rng = np.random.default_rng(18)
+    N, K, budget, steps = (2, 256, 6.0, 3) if case == "full_width" else (3, 12, 0.0, 2) if case == "no_budget" else (2, 5, 8.0, 2)
+    planes = np.stack([rng.integers(0, 60, (N, K)), rng.random((N, K)) * 6, rng.uniform(0.0, 0.3, (N, K)), rng.uniform(0.05, 0.15, (N, K)),
+                       rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.3, 1.5, (N, K)),
+                       rng.uniform(0.02, 0.3, (N, K))]).astype(np.float32)
+    if case == "huge_cells":
+        planes[0], planes[1] = 7000.0, 50.0
+    e = amd.StepEngine(N, K, model=2, seed=14, drift_enabled=True)
+    e.set_general_model(9, 0.5, 1)
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes, drift_on=True, max_bidders=9, participation_rate=0.5, num_winners=1)
+    for _ in range(steps):
+        bids = o.sample_bids(0.05, 0.5)
+        got, ref = e.step(bids, budget), o.step(bids, budget)
+        H.assert_step_equal(got, ref, implicit=False)
+    o.materialize_drift()
+    assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+
+
 def test_g8_env_episodes_on_gpu(amd, golden):
     for ep in golden("g8_env_episodes.json")["episodes"]:
         K = ep["K"]
