@@ -500,6 +500,13 @@ class ShardedStepEngine:
     def _each(self):
         return zip(self.parts, self.bounds[:-1], self.bounds[1:])
 
+    def __getattr__(self, name):
+        # (only reached for names this class does not define: the device-resident agent / metric / curve calls of StepEngine)
+        if hasattr(StepEngine, name):
+            raise NotImplementedError(f"{name}() works on one engine: construct the env / engine with engine_shards=1 "
+                                      "(several engines per device only serve the host-in / host-out step)")
+        raise AttributeError(name)
+
     def close(self):
         self.out, self._bids_stage, self._budget_stage, self._flat_act, self._flat_obs = {}, None, None, None, None
         self._counts_u16, self._overflow, self._small = None, None, []
