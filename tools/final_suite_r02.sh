@@ -21,5 +21,6 @@ timeout -k 10 200 python3 tools/measure_small_env.py > $OUT/small_env.txt 2>&1 |
 echo "timings done"
 timeout -k 10 300 python3 tools/soak_parity.py 150 101 > $OUT/soak_implicit.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 150 102 explicit > $OUT/soak_explicit.txt 2>&1 || exit 1
-tail -1 $OUT/soak_implicit.txt $OUT/soak_explicit.txt
+timeout -k 10 300 python3 tools/soak_parity.py 150 103 general > $OUT/soak_general.txt 2>&1 || exit 1
+tail -n1 $OUT/soak_implicit.txt; tail -n1 $OUT/soak_explicit.txt; tail -n1 $OUT/soak_general.txt
 echo done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle soak: random shapes, keyword laws, budgets, drift, autoreset; every step compared
-bit for bit.  Usage: python tools/soak_parity.py [seconds] [seed]"""
+bit for bit.  Usage: python tools/soak_parity.py [seconds] [seed] [explicit | general]"""
 import sys
 import time
 
@@ -14,6 +14,7 @@ from tests import helpers as H  # noqa: E402
 budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 explicit = len(sys.argv) > 3 and sys.argv[3] == "explicit"      # the default-constructor (ExplicitKeyword) model
+general = len(sys.argv) > 3 and sys.argv[3] == "general"        # the default ImplicitKeyword (bidder pools, top-(w+n) clearing)
 t0 = time.time()
 cases = steps = reruns = 0
 last_report = t0
@@ -35,21 +36,32 @@ while time.time() - t0 < budget_s:
         planes = H.explicit_params(N, K, seed=int(rng.integers(1 << 30)))
         if rng.random() < 0.3:
             planes[0] *= np.float32(rng.choice([0.0, 4.0]))          # no volume / ~100 auctions
+    pool = None
+    if general:                                   # tens of competitor bids per auction: keep the oracle's share of the time small
+        K = min(K, 257)
+        planes = H.implicit_params(N, K, seed=int(rng.integers(1 << 30)), mean_volume=float(rng.choice([0, 3, 20, 60])), cvr=float(rng.uniform(0, 1)),
+                                   no_vol_prob=float(rng.choice([0.0, 0.3])))
+        planes[2] = rng.uniform(0.0, 0.3, planes[2].shape).astype(np.float32)         # competitors' Laplace location ...
+        planes[3] = rng.uniform(0.02, 0.2, planes[3].shape).astype(np.float32)        # ... and scale (raw bids, not 1 / scale)
+        pool = (int(rng.choice([1, 3, 9, 30, 70])), float(rng.choice([0.2, 0.6, 1.0])), int(rng.integers(1, 3)))
     drift = bool(rng.random() < 0.4)
     auto = bool(rng.random() < 0.5)
     max_days = int(rng.integers(1, 5))
     loss = float(rng.choice([1e9, 20.0]))
-    e = StepEngine(N, K, model=1 if explicit else 0, seed=int(rng.integers(1 << 30)), drift_enabled=drift, drift=(0.1, 0.2, 0.3), max_days=max_days,
+    e = StepEngine(N, K, model=1 if explicit else 2 if general else 0, seed=int(rng.integers(1 << 30)), drift_enabled=drift, drift=(0.1, 0.2, 0.3), max_days=max_days,
                    loss_threshold=loss, auto_reset=auto)
+    if general:
+        e.set_general_model(*pool)
     e.set_all_params(planes)
     e.reset(seeds=rng.integers(0, 1 << 40, N).astype(np.uint64))
-    o = H.mirror_oracle(e, planes, drift_on=drift, drift=(0.1, 0.2, 0.3), max_days=max_days, loss_threshold=loss, auto_reset=auto)
+    extra = dict(max_bidders=pool[0], participation_rate=pool[1], num_winners=pool[2]) if general else {}
+    o = H.mirror_oracle(e, planes, drift_on=drift, drift=(0.1, 0.2, 0.3), max_days=max_days, loss_threshold=loss, auto_reset=auto, **extra)
     for s in range(int(rng.integers(1, 6))):
         bids = o.sample_bids(float(rng.uniform(0.01, 0.6)), float(rng.uniform(0.6, 2.0)))
         budget = rng.choice([1e9, 500.0, 50.0, 5.0, 0.3, 0.0], size=N).astype(np.float32)
         got, ref = e.step(bids, budget), o.step(bids, budget)
         try:
-            H.assert_step_equal(got, ref, implicit=not explicit)
+            H.assert_step_equal(got, ref, implicit=not (explicit or general))
         except AssertionError:
             print("MISMATCH", dict(N=N, K=K, mv=mv, drift=drift, auto=auto, step=s, budget=budget.tolist()))
             raise
