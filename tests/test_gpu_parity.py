@@ -415,6 +415,34 @@ def test_results_do_not_depend_on_sharding(amd):
     whole.close()
 
 
+@pytest.mark.parametrize("budget", [1e9, 3.0])
+def test_two_million_envs_of_few_keywords(amd, budget):
+    """the env axis at 2^21 (index arithmetic, flagged lists and ticket counters far beyond the grid; narrow keyword tiles):
+    the last 48 envs equal a 48-env engine placed at the same global ids, which in turn equals the oracle"""
+    N, K, T = 1 << 21, 6, 48
+    rng = np.random.default_rng(77)
+    tail = H.implicit_params(T, K, seed=78, mean_volume=40)
+    e = amd.StepEngine(N, K, seed=1234, max_days=3, auto_reset=True)
+    row = H.implicit_params(1, K, seed=79, mean_volume=40)
+    e.set_all_params(np.concatenate([np.broadcast_to(row, (8, N - T, K)), tail], axis=1))
+    e.reset()
+    small = amd.StepEngine(T, K, seed=1234, max_days=3, auto_reset=True, env_id_base=N - T)
+    small.set_all_params(tail)
+    small.reset()
+    o = H.mirror_oracle(small, tail, max_days=3, auto_reset=True)
+    bids_tail = np.round(rng.uniform(0.3, 1.0, (T, K)), 2).astype(np.float32)
+    bids = np.full((N, K), 0.55, np.float32)
+    bids[N - T:] = bids_tail
+    for _ in range(4):                                   # crosses an episode end
+        big, sm, ref = e.step(bids, budget, copy=False), small.step(bids_tail, budget), o.step(bids_tail, budget)
+        H.assert_step_equal(sm, ref)
+        for k in sm:
+            assert np.array_equal(big[k][N - T:], sm[k]), k
+        assert big["impressions"][: N - T].sum() > 0 and (big["days_passed"][: N - T] == big["days_passed"][0]).all()
+    e.close()
+    small.close()
+
+
 def test_synthetic_actions_match_oracle(amd):
     N, K = 3, 130
     e = amd.StepEngine(N, K, seed=5)
