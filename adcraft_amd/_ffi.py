@@ -122,6 +122,7 @@ def lib():
         "adc_engine_set_flat_actions_device": ([vp, vp], C.c_int),
         "adc_engine_flat_obs_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_profile_enable": ([vp, C.c_int], C.c_int),
+        "adc_engine_profile_sample_every": ([vp, C.c_int32], C.c_int),
         "adc_engine_profile_read": ([vp, vp, C.POINTER(i64)], C.c_int),
         "adc_engine_metrics_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_metrics_reset": ([vp], C.c_int),

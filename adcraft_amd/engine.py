@@ -295,11 +295,13 @@ class StepEngine:
         return p.value
 
     # ---- measurement / metrics
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=True, every=1):
+        """HIP events around the kernels of every `every`-th step (recording them costs ~16 us a step: sample when timing)"""
+        check(self._lib.adc_engine_profile_sample_every(self._h, int(every)))
         check(self._lib.adc_engine_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self):
-        """(ms_fast_pass, ms_exact_pass_and_tail, ms_metric_accumulate), steps - summed over the steps since the last read"""
+        """(ms_fast_pass, ms_exact_pass_and_tail, ms_metric_accumulate), measured steps - summed since the last read"""
         ms = (C.c_double * 3)()
         n = C.c_int64()
         check(self._lib.adc_engine_profile_read(self._h, ms, C.byref(n)))

@@ -34,6 +34,7 @@ BYTES_PER_ENV = 26
 MAX_DAYS = 60
 # the three intervals between the engine's HIP events; the IMPLICIT kernels add their metric sums in their own output phase, so
 # the third interval holds no kernel here (what it shows is the cost of recording an event pair)
+PROFILE_EVERY = 8          # steps between event-bracketed steps inside the timed region (fewer for short runs: >= 25 samples)
 KERNEL_NAMES = ("k_step_implicit_fast", "k_tail_or_flag + k_step_exact_rows (step tail)", "(no kernel: event-record overhead)")
 # the reference's own Python loop, unmodified, on this keyword law: measured in the BUILD container (tools/time_reference_python.py,
 # one Xeon core @ 2.1 GHz, stand-ins for the two modules that cannot be imported there) - never on the GPU box, where
@@ -112,7 +113,8 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
     red.metric_sums(ideal_k * warmup, ideal_pos_k * warmup)       # also brings the collective path up outside the timed region
     barrier()
     eng.metrics_reset()
-    eng.profile_enable(True)
+    every = max(1, min(PROFILE_EVERY, steps // 25))
+    eng.profile_enable(True, every=every)
     eng.profile_read()
     barrier()
     t0 = time.perf_counter()
@@ -146,7 +148,10 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": notes.get("hbm_bytes_per_launch"),
                      "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else None),
-                     "kernel": KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches),
+                     "kernel": KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps,
+                     "kernel_ms_method": f"HIP events on the engine's stream around every {every}. step of the timed region (four event "
+                                         "records a step cost ~16 us of throughput; rocprofv3 --kernel-trace --stats of the same "
+                                         "command: profiles/r02_final_rocprof_summary.md)",
                      "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(KERNEL_NAMES, kernel_ms)},
                      "algorithmic_bytes_per_launch": b_alg},
     }
