@@ -255,7 +255,10 @@ def run_rank(args):
             "config": {"workload": main["workload"], "envs_per_gpu": main["envs_per_gpu"], "keywords": main["keywords"],
                        "parallelism": f"env-sharded x{main['n_gpus']}",
                        "collective": ("none on the step path; RCCL all-reduce of the episode-metric vector once per episode "
-                                      "(adc_engine_metrics_allreduce)") if world > 1 else "none (single GPU)"},
+                                      "(adc_engine_metrics_allreduce)") if world > 1 else "none (single GPU)",
+                       # N = 1 measures BASELINE configs[1] (cfg2); N > 1 measures the 8-GPU config's per-GPU shard (cfg4):
+                       # the one-GPU point of that weak-scaling curve is also.cfg4.value of the N = 1 line
+                       "weak_scaling_reference": "also.cfg4.value of the N=1 line (same per-GPU shard as the N>1 runs)"},
             "env_steps_per_s": main["env_steps_per_s"],
             "roofline": main["roofline"],
         }
