@@ -328,3 +328,34 @@ def test_compact_counts_are_the_same_counts_as_uint16(pkg):
     with pytest.raises(OverflowError):
         eng.step(np.full((2, 4), 5.0, np.float32), np.full(2, 1e9, np.float32))
     eng.close()
+
+
+def test_profiling_can_sample_and_sharded_engine_names_what_it_lacks(pkg):
+    """adc_engine_profile_sample_every: events around every n-th step only (measured launches = ceil(steps / n), same results);
+    a ShardedStepEngine refuses the single-engine calls by name instead of failing on a missing attribute"""
+    from adcraft_amd.engine import ShardedStepEngine, StepEngine
+    N, K = 6, 32
+    planes = np.broadcast_to(np.array([40, 6, 0.5, 0.2, 0.3, 0.5, 1.0, 0.2], np.float32)[:, None, None], (8, N, K)).copy()
+    outs = []
+    for every in (1, 3):
+        e = StepEngine(N, K, seed=5)
+        e.set_all_params(planes)
+        e.reset()
+        e.sample_actions(0.3, 1.0, 1e9)
+        e.profile_enable(True, every=every)
+        e.profile_read()
+        for _ in range(7):
+            e.step_device()
+        ms, launches = e.profile_read()
+        assert launches == (7 if every == 1 else 3) and ms[0] > 0.0
+        outs.append(e.fetch())
+        e.close()
+    assert all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+    with pytest.raises(ValueError):
+        StepEngine(1, 4).profile_enable(True, every=0)
+    s = ShardedStepEngine(N, K, shards=2, seed=5)
+    with pytest.raises(NotImplementedError, match="engine_shards=1"):
+        s.agent_init(1.0, None)
+    with pytest.raises(AttributeError):
+        s.no_such_call
+    s.close()
