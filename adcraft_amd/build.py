@@ -14,9 +14,8 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libadcraft_hip.so")
 SOURCES = ["adc_engine.hip", "adc_shims.cpp"]
-HEADERS = ["adc_law.h", os.path.join(ROOT, "include", "adcraft_engine.h")] + [
-    os.path.join("parts", f) for f in ("common.inc", "kernel_fast.inc", "kernel_exact_serial.inc", "kernel_exact_rows.inc", "kernel_explicit_fast.inc",
-                                       "kernels_misc.inc", "kernels_policy.inc", "host_api.inc")]
+HEADERS = ["adc_law.h", os.path.join(ROOT, "include", "adcraft_engine.h")] + sorted(
+    os.path.join("parts", f) for f in os.listdir(os.path.join(SRC_DIR, "parts")) if f.endswith(".inc"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
          "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
