@@ -139,6 +139,9 @@ def lib():
         "adc_binomial": ([u64, f64, u64, u64], u64),
         "adc_cost_create": ([f64, i64, u64, u64, vp], C.c_int),
         "adc_auction_word_intervals": ([f32, f32, f32, f32, vp], C.c_int),
+        "adc_auction_word_brackets": ([f32, f32, f32, f32, vp], C.c_int),
+        "adc_check_win_brackets": ([i64, vp, vp, vp, vp, vp, vp, vp], i64),
+        "adc_debug_win_brackets_device": ([C.c_int, i64, vp, vp, vp, vp, vp], C.c_int),
         "adc_comm_get_unique_id": ([vp], C.c_int),
         "adc_engine_comm_init": ([vp, vp, i32, i32], C.c_int),
         "adc_engine_comm_destroy": ([vp], C.c_int),

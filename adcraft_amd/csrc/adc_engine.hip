@@ -48,6 +48,7 @@
 namespace adck {
 #include "parts/common.inc"
 #include "parts/kernel_fast.inc"
+#include "parts/kernel_sparse.inc"
 #include "parts/kernel_exact_rows.inc"
 #include "parts/kernel_exact_serial.inc"
 #include "parts/kernel_explicit_fast.inc"

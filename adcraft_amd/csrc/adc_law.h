@@ -279,6 +279,17 @@ ADC_HD LogTableEntry log_table_entry(int i)
     return LogTableEntry{a, (b - a) * 3.0517578125e-05f};
 }
 
+// the table as its node values alone (kLogTableIntervals + 1 floats: half the bytes, for LDS copies): the slope is rebuilt
+// from two neighbouring nodes with the operations log_table_entry used, so both forms give the same bits
+struct LogNodes { const float *nodes; };
+ADC_HD LogTableEntry log_entry(const LogTableEntry *tab, uint32_t i) { return tab[i]; }
+ADC_HD LogTableEntry log_entry(LogNodes t, uint32_t i)
+{
+    const float a = t.nodes[i], b = t.nodes[i + 1];
+    return LogTableEntry{a, (b - a) * 3.0517578125e-05f};
+}
+ADC_HD float log_table_node(int i) { return det_log(1.0f + (float)i * 0.00390625f); }      // i = 0 .. kLogTableIntervals
+
 ADC_HD float neg_log_u24(uint32_t w24, const LogTableEntry *tab)
 {
     const uint32_t bits = float_to_bits((float)w24);                 // exact: w24 < 2^24
@@ -350,19 +361,21 @@ ADC_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 // non-decreasing in v (every step is a correctly rounded monotone operation), so {v : bid > cents(v)} is an interval - which
 // is what lets the step kernels resolve an auction by comparing its word with per-keyword thresholds.
 // neg_log_u24 with its argument already a float (an odd integer below 2^24, exactly representable)
-ADC_HD float neg_log_f24(float w24, const LogTableEntry *tab)
+template <typename Tab>
+ADC_HD float neg_log_f24(float w24, Tab tab)
 {
     const uint32_t bits = float_to_bits(w24);
     const float ef = (float)((int)(bits >> 23) - 151);
     const uint32_t mant = bits & 0x007FFFFFu;
-    const LogTableEntry t = tab[mant >> 15];
+    const LogTableEntry t = log_entry(tab, mant >> 15);
     float r = fma32(t.slope, (float)(mant & 0x7FFFu), t.value);
     r = fma32(ef, -2.12194440e-4f, r);
     r = fma32(ef, 0.693359375f, r);
     return -r;
 }
 
-ADC_HD float laplace_deviate_from_v(uint32_t v24, const LogTableEntry *tab)
+template <typename Tab>
+ADC_HD float laplace_deviate_from_v(uint32_t v24, Tab tab)
 {
     const uint32_t neg_mask = 0u - (v24 >> 23);                                  // all ones on the positive side
     const uint32_t mag = (v24 ^ neg_mask) & 0x007FFFFFu;
@@ -371,7 +384,8 @@ ADC_HD float laplace_deviate_from_v(uint32_t v24, const LogTableEntry *tab)
 }
 
 // round(100 X) with its sign, clamped to +-1e9: non-decreasing in v.  |.| of it is the competitor's bid in cents.
-ADC_HD int32_t signed_cents_from_v(uint32_t v24, float loc, float scale, const LogTableEntry *tab)
+template <typename Tab>
+ADC_HD int32_t signed_cents_from_v(uint32_t v24, float loc, float scale, Tab tab)
 {
     const float x = fma32(__builtin_fabsf(scale), laplace_deviate_from_v(v24, tab), loc);
     float c = __builtin_rintf(x * 100.0f);
@@ -381,7 +395,8 @@ ADC_HD int32_t signed_cents_from_v(uint32_t v24, float loc, float scale, const L
 }
 
 // |signed_cents_from_v|: rint and the clamp are odd-symmetric, so |round(100 x)| = round(100 |x|)
-ADC_HD int32_t competitor_cents_from_v(uint32_t v24, float loc, float scale, const LogTableEntry *tab)
+template <typename Tab>
+ADC_HD int32_t competitor_cents_from_v(uint32_t v24, float loc, float scale, Tab tab)
 {
     const float x = fma32(__builtin_fabsf(scale), laplace_deviate_from_v(v24, tab), loc);
     float c = __builtin_rintf(__builtin_fabsf(x) * 100.0f);
@@ -405,7 +420,8 @@ ADC_HD bool auction_wins(uint32_t w, int32_t bid_c, int32_t comp_c) { return bid
 
 // auction_outcome for callers that apply auction_wins right away: the click of the word 2^32 - 1 (the only word the
 // saturated threshold 0xFFFFFFFF = "always" is needed for) is immaterial because that word never wins
-ADC_HD int32_t auction_outcome_unless_top_word(uint32_t w, const AuctionLaw &a, float loc, float scale, const LogTableEntry *tab, bool &click)
+template <typename Tab>
+ADC_HD int32_t auction_outcome_unless_top_word(uint32_t w, const AuctionLaw &a, float loc, float scale, Tab tab, bool &click)
 {
     click = w < a.t32;
     const uint32_t d = click ? w : w - a.t32;
@@ -499,6 +515,89 @@ ADC_HD WinIntervals win_intervals(int32_t bid_c, float loc, float scale, uint64_
     return r;
 }
 
+// ---- conservative brackets of the two win intervals (keyword sets with few auctions per keyword) -------------------
+// win_intervals costs several hundred instructions per keyword (two verified bisections, four f64 quotients): right for a
+// keyword with a hundred auctions a day, not for one with ten.  win_brackets gives, from the float estimate ALONE (one
+// reciprocal, two exp2, no table look-up, no verification), two pairs of word intervals with
+//     in.c  subset of  {clicked wins}  subset of  out.c,        in.n  subset of  {unclicked wins}  subset of  out.n
+// so a word inside `in` wins, a word outside `out` loses, and only the words in between - a few 1e-5 of all words - have to
+// be resolved the long way (auction_outcome_unless_top_word + auction_wins, what the oracle does for every auction).
+// Results therefore never depend on the estimate, only the share of words that take the long way does.
+//
+// Error budget of the estimate v^ of W = lower_bound_v(target), relative to mag = 2^23 u (the table's side of the
+// distribution): table log and its float evaluation < 8e-6; the float evaluation of z_t = ((target - 1/2)/100 - loc)/s and
+// of x = loc + s z on the law's side 3.6e-7 (|x_t| + |loc|)/s + 1.2e-7 |z_t|; exp2 and its argument < 1.3e-6; + a few
+// units for the integer steps.  `slack` below is more than twice that; tests/test_oracle_scalar.py checks the inclusions
+// against win_intervals on 10^7 random and adversarial keywords, tests/test_gpu_parity.py on the device's own exp2 / rcp.
+// Word space: D(W) = ceil(W 2^32 / m) with m = floor(2^56 / range) good to 2^-23, saturated for range < 2^24, i.e.
+// D(W) = W max(range 2^-24, 1) (1 +- 2^-22) + [0, 1); float32 carries words to +-256.  kWordSlack covers both.
+struct WinBrackets { WinIntervals out, in; };
+constexpr float kWordSlack = 4096.0f;
+
+ADC_HD float fast_exp2(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return exp2f(x);
+#endif
+}
+ADC_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+ADC_HD float min_num(float a, float b) { return __builtin_fminf(a, b); }       // the non-NaN operand if one is NaN
+ADC_HD float max_num(float a, float b) { return __builtin_fmaxf(a, b); }
+ADC_HD uint32_t sat_sub(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }      // v_sub_u32 ... clamp
+// float -> uint32: truncation, saturating at both ends, NaN -> 0 (v_cvt_u32_f32 does exactly this; spelled out for the host)
+ADC_HD uint32_t to_word(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)x;
+#else
+    return !(x > 0.0f) ? 0u : x >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)x;
+#endif
+}
+
+// v^ and its slack for one target; x_t = (target - 1/2) / 100 is passed in
+ADC_HD void lower_bound_estimate(float x_t, float loc, float inv_s, float &est, float &slack)
+{
+    const float z_t = (x_t - loc) * inv_s;
+    const float e_t = __builtin_fabsf(z_t);
+    const float mag = min_num(fast_exp2(fma32(e_t, -1.44269504f, 23.0f)), 8388607.0f);
+    est = z_t < 0.0f ? mag : 16777215.0f - mag;
+    const float rel = fma32(1.0e-6f, fma32(__builtin_fabsf(x_t) + __builtin_fabsf(loc), inv_s, e_t), 2.0e-5f);
+    slack = min_num(fma32(mag, rel, 16.0f), 33554432.0f);                   // (NaN -> 2^25: everything is "in between")
+}
+
+// t_f = the click threshold T as the float32 it is (bernoulli_threshold_f32(bctr), an integer <= 2^32)
+ADC_HD WinBrackets win_brackets(int32_t bid_c, float loc, float scale, float t_f)
+{
+    const float inv_s = fast_rcp(__builtin_fabsf(scale));
+    const float bc = (float)bid_c;
+    float lo, lo_s, hi, hi_s;
+    lower_bound_estimate(fma32(bc, -0.01f, 0.005f), loc, inv_s, lo, lo_s);      // target 1 - bid_c
+    lower_bound_estimate(fma32(bc, 0.01f, -0.005f), loc, inv_s, hi, hi_s);      // target bid_c
+    const float lo_out = lo - lo_s, lo_in = lo + lo_s, hi_out = hi + hi_s, hi_in = hi - hi_s;
+    const float a_c = max_num(t_f * 5.9604644775390625e-08f, 1.0f);
+    const float a_n = max_num((4294967296.0f - t_f) * 5.9604644775390625e-08f, 1.0f);
+    const float t_dn = t_f - kWordSlack, t_up = t_f + kWordSlack;
+    WinBrackets r;
+    // clicked wins live in [0, T): both upper ends stop there
+    const uint32_t c_lo_out = to_word(fma32(lo_out, a_c, -kWordSlack)), c_hi_out = to_word(min_num(fma32(hi_out, a_c, kWordSlack), t_f));
+    const uint32_t c_lo_in = to_word(fma32(lo_in, a_c, kWordSlack)), c_hi_in = to_word(min_num(fma32(hi_in, a_c, -kWordSlack), t_f));
+    // unclicked wins in [T, 2^32 - 1): the conversion saturates at 2^32 - 1, the one word that never wins
+    const uint32_t n_lo_out = to_word(fma32(lo_out, a_n, t_dn)), n_hi_out = to_word(fma32(hi_out, a_n, t_up));
+    const uint32_t n_lo_in = to_word(fma32(lo_in, a_n, t_up)), n_hi_in = to_word(fma32(hi_in, a_n, t_dn));
+    r.out = WinIntervals{c_lo_out, sat_sub(c_hi_out, c_lo_out), n_lo_out, sat_sub(n_hi_out, n_lo_out)};
+    r.in = WinIntervals{c_lo_in, sat_sub(c_hi_in, c_lo_in), n_lo_in, sat_sub(n_hi_in, n_lo_in)};
+    return r;
+}
+
 // the clicked-win interval alone, for a bid: win_intervals(bid_c, ...).c_lo / .c_w.  With bid_c = min(bid, R + 1) these are the
 // words whose clicked win costs at most R cents (a win pays the competitor's cents, and wins iff they are below the bid)
 ADC_HD void clicked_win_interval(int32_t bid_c, float loc, float scale, uint64_t t_click, const AuctionLaw &law, const LogTableEntry *tab,
@@ -545,6 +644,14 @@ ADC_HD int64_t bid_to_cents(float bid)
     if (!(c >= 1.0)) c = 1.0;
     if (c > 1.0e9) c = 1.0e9;
     return (int64_t)c;
+}
+// the same value as a 32-bit integer (it is at most 1e9): one f64 -> i32 conversion instead of the f64 -> i64 sequence
+ADC_HD int32_t bid_to_cents_i32(float bid)
+{
+    double c = __builtin_rint((double)bid * 100.0);
+    if (!(c >= 1.0)) c = 1.0;
+    if (c > 1.0e9) c = 1.0e9;
+    return (int32_t)c;
 }
 ADC_HD int64_t budget_to_cents(float budget)
 {

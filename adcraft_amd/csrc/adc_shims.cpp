@@ -90,18 +90,77 @@ ADC_EXPORT int adc_cost_create(double x, int64_t n, uint64_t seed, uint64_t coun
 // (w - out[0]) < out[1] and an unclicked win iff (w - out[2]) < out[3] in unsigned 32-bit arithmetic.  Diagnostic entry
 // point: lets a caller (and tests/test_abi_and_host.py) check the thresholds against auction-by-auction resolution
 // (adcraft/synthetic_kw_helpers.py:116-180 on the sampled competitor bid) without a GPU.
-ADC_EXPORT int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out4)
+static const adc::LogTableEntry *host_log_table()
 {
-    if (!out4) return ADC_EINVAL;
     static adc::LogTableEntry table[adc::kLogTableIntervals];
     static bool ready = false;
     if (!ready) {
         for (int i = 0; i < adc::kLogTableIntervals; ++i) table[i] = adc::log_table_entry(i);
         ready = true;
     }
+    return table;
+}
+
+ADC_EXPORT int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out4)
+{
+    if (!out4) return ADC_EINVAL;
+    const adc::LogTableEntry *table = host_log_table();
     const adc::AuctionLaw law = adc::make_auction_law(buyside_ctr);
     const adc::WinIntervals r = adc::win_intervals((int32_t)adc::bid_to_cents(bid), cost_loc, cost_scale,
                                                    adc::bernoulli_threshold(buyside_ctr), law, table);
     out4[0] = r.c_lo; out4[1] = r.c_w; out4[2] = r.n_lo; out4[3] = r.n_w;
     return ADC_OK;
+}
+
+// The conservative brackets of those two intervals that k_step_implicit_sparse classifies auctions with (adc_law.h
+// win_brackets): out8 = {outer c_lo, c_w, n_lo, n_w, inner c_lo, c_w, n_lo, n_w}.  Host evaluation of the same code (the
+// device's exp2 / rcp differ in the last bits; both stay inside the slack - adc_engine_debug_win_brackets is the device's).
+ADC_EXPORT int adc_auction_word_brackets(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out8)
+{
+    if (!out8) return ADC_EINVAL;
+    const adc::WinBrackets b = adc::win_brackets((int32_t)adc::bid_to_cents(bid), cost_loc, cost_scale, adc::bernoulli_threshold_f32(buyside_ctr));
+    out8[0] = b.out.c_lo; out8[1] = b.out.c_w; out8[2] = b.out.n_lo; out8[3] = b.out.n_w;
+    out8[4] = b.in.c_lo; out8[5] = b.in.c_w; out8[6] = b.in.n_lo; out8[7] = b.in.n_w;
+    return ADC_OK;
+}
+
+// [lo, lo + w) as a pair of 64-bit ends; an empty interval has w == 0
+static inline bool interval_inside(uint32_t a_lo, uint32_t a_w, uint32_t b_lo, uint32_t b_w)
+{
+    if (a_w == 0u) return true;
+    return b_w != 0u && a_lo >= b_lo && (uint64_t)a_lo + a_w <= (uint64_t)b_lo + b_w;
+}
+
+// Checks inner subset-of exact subset-of outer for n keywords; brackets8 == NULL: the host's own win_brackets, otherwise the given
+// ones (8 words per keyword, e.g. computed on the device).  Returns the number of keywords that violate an inclusion
+// (first_bad = index of the first, or -1); *ambiguous_words (optional) = total width of the in-between zones, the
+// long-way share of the stream.
+ADC_EXPORT int64_t adc_check_win_brackets(int64_t n, const float *bid, const float *cost_loc, const float *cost_scale, const float *buyside_ctr,
+                                          const uint32_t *brackets8, int64_t *first_bad, double *ambiguous_words)
+{
+    if (n < 0 || !bid || !cost_loc || !cost_scale || !buyside_ctr) return -1;
+    const adc::LogTableEntry *table = host_log_table();
+    int64_t bad = 0, first = -1;
+    double amb = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t bid_c = (int32_t)adc::bid_to_cents(bid[i]);
+        const adc::AuctionLaw law = adc::make_auction_law(buyside_ctr[i]);
+        const adc::WinIntervals x = adc::win_intervals(bid_c, cost_loc[i], cost_scale[i], adc::bernoulli_threshold(buyside_ctr[i]), law, table);
+        adc::WinBrackets b;
+        if (brackets8) {
+            const uint32_t *p = brackets8 + 8 * i;
+            b.out = adc::WinIntervals{p[0], p[1], p[2], p[3]};
+            b.in = adc::WinIntervals{p[4], p[5], p[6], p[7]};
+        } else {
+            b = adc::win_brackets(bid_c, cost_loc[i], cost_scale[i], adc::bernoulli_threshold_f32(buyside_ctr[i]));
+        }
+        const bool ok = interval_inside(b.in.c_lo, b.in.c_w, x.c_lo, x.c_w) && interval_inside(x.c_lo, x.c_w, b.out.c_lo, b.out.c_w) &&
+                        interval_inside(b.in.n_lo, b.in.n_w, x.n_lo, x.n_w) && interval_inside(x.n_lo, x.n_w, b.out.n_lo, b.out.n_w) &&
+                        (uint64_t)b.out.c_lo + b.out.c_w <= 0xFFFFFFFFull && (uint64_t)b.out.n_lo + b.out.n_w <= 0xFFFFFFFFull;
+        if (!ok) { if (first < 0) first = i; ++bad; }
+        amb += ((double)b.out.c_w - (double)b.in.c_w) + ((double)b.out.n_w - (double)b.in.n_w);
+    }
+    if (first_bad) *first_bad = first;
+    if (ambiguous_words) *ambiguous_words = amb;
+    return bad;
 }

@@ -373,6 +373,16 @@ int adc_cost_create(double x, int64_t n, uint64_t seed, uint64_t counter, double
  * (uint32 arithmetic) - equivalent, word for word, to sampling the competitor's bid and running the reference's
  * nth_price_auction env path on it (adcraft/synthetic_kw_helpers.py:116-180: win iff bid > competitor) */
 int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out4);
+/* diagnostic: the conservative BRACKETS of those two intervals that k_step_implicit_sparse classifies a sparse keyword's
+ * auctions with (adc_law.h win_brackets): out8 = {outer c_lo, c_w, n_lo, n_w, inner c_lo, c_w, n_lo, n_w}; a word inside an
+ * inner interval wins, a word outside the outer ones loses, the rest is resolved from the sampled competitor bid.
+ * adc_check_win_brackets verifies inner <= exact <= outer for n keywords (brackets8 NULL: the host's own evaluation;
+ * otherwise e.g. adc_debug_win_brackets_device's) and returns the number of violations (0 expected). */
+int adc_auction_word_brackets(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out8);
+int64_t adc_check_win_brackets(int64_t n, const float *bid, const float *cost_loc, const float *cost_scale, const float *buyside_ctr,
+                               const uint32_t *brackets8, int64_t *first_bad, double *ambiguous_words);
+int adc_debug_win_brackets_device(int device_id, int64_t n, const float *bid, const float *cost_loc, const float *cost_scale,
+                                  const float *buyside_ctr, uint32_t *out8);
 
 #ifdef __cplusplus
 }

@@ -292,3 +292,51 @@ def test_word_space_intervals_equal_auction_by_auction_resolution():
             if win:
                 assert cw == bool(click.value)
     assert n_edges > 500
+
+
+def _bracket_keywords(rng, n):
+    """keyword laws for the bracket checks: the BASELINE laws, wide log-uniform ranges, and degenerate corners"""
+    third = n // 3
+    bid = np.empty(n, np.float32); loc = np.empty(n, np.float32); scale = np.empty(n, np.float32); ctr = np.empty(n, np.float32)
+    a = slice(0, third)
+    bid[a] = rng.uniform(0.3, 1.0, third); loc[a] = rng.uniform(0.3, 1.0, third)
+    scale[a] = np.maximum(0.01, rng.uniform(0.01, 0.3, third) * loc[a]); ctr[a] = rng.uniform(0.1, 0.9, third)
+    b = slice(third, 2 * third)
+    bid[b] = np.exp(rng.uniform(-5, 5, third)); loc[b] = np.exp(rng.uniform(-5, 5, third)) * rng.choice([-1.0, 1.0], third, p=[0.2, 0.8])
+    scale[b] = np.exp(rng.uniform(-8, 4, third)); ctr[b] = np.where(rng.random(third) < 0.1, np.exp(-20 * rng.random(third)), rng.random(third))
+    c = slice(2 * third, n)
+    m = n - 2 * third
+    bid[c] = np.rint(rng.uniform(1, 300, m)) / 100.0; loc[c] = rng.uniform(-0.5, 1.5, m); scale[c] = np.exp(rng.uniform(-14, 2, m))
+    ctr[c] = rng.choice([0.0, 1.0, 1e-9, 1.0 - 1e-7, 0.5], m) * np.where(rng.random(m) < 0.5, 1.0, rng.random(m))
+    for arr, vals in ((loc, [np.nan, np.inf, -np.inf, 0.0]), (scale, [np.nan, np.inf, 0.0, -0.08]), (bid, [np.nan, np.inf, -3.0, 1e7, 0.01])):
+        idx = rng.integers(0, n, 4 * len(vals))
+        arr[idx] = np.tile(np.array(vals, np.float32), 4)
+    return bid, loc, scale, ctr
+
+
+def test_win_brackets_enclose_the_exact_intervals():
+    """adc_law.h win_brackets (what k_step_implicit_sparse classifies auctions with) against win_intervals (the exact word
+    intervals, themselves checked word by word against the oracle above): inner <= exact <= outer for every keyword - BASELINE
+    laws, log-uniform parameter ranges, zero / NaN / infinite / negative corners - and the in-between zone (the words that take
+    the long way) stays a ~1e-5 share of the stream on the BASELINE laws."""
+    import ctypes as C
+    L = _ffi.lib()
+    rng = np.random.default_rng(31)
+    n = 600_000
+    bid, loc, scale, ctr = _bracket_keywords(rng, n)
+    first, amb = C.c_int64(-1), C.c_double(0.0)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    bad = L.adc_check_win_brackets(n, ptr(bid), ptr(loc), ptr(scale), ptr(ctr), None, C.byref(first), C.byref(amb))
+    assert bad == 0, (bad, first.value, bid[first.value], loc[first.value], scale[first.value], ctr[first.value])
+    third = n // 3
+    L.adc_check_win_brackets(third, ptr(bid), ptr(loc), ptr(scale), ptr(ctr), None, C.byref(first), C.byref(amb))
+    assert amb.value / third / 2.0**32 < 1e-4
+    # the single-keyword form returns what the batch checker saw; a degenerate competitor scale makes everything "in between"
+    out = (C.c_uint32 * 8)()
+    assert L.adc_auction_word_brackets(0.7, 0.55, 0.0, 0.3, out) == 0
+    assert out[5] == 0 and out[7] == 0 and out[1] > 0
+    assert L.adc_auction_word_brackets(0.7, 0.55, 0.08, 0.5, out) == 0
+    x = (C.c_uint32 * 4)()
+    assert L.adc_auction_word_intervals(0.7, 0.55, 0.08, 0.5, x) == 0
+    assert out[0] <= x[0] <= out[4] and out[4] + out[5] <= x[0] + x[1] <= out[0] + out[1]
+    assert 0 < (out[1] - out[5]) < 2**18 and out[5] > 2**28

@@ -55,6 +55,77 @@ def test_sparse_volume_keywords(amd):
     _run_vs_oracle(amd, 6, 320, planes, steps=4, budget=1.0e9)
 
 
+@pytest.mark.parametrize("case", ["cfg3_law", "ragged_tiles", "beyond_the_item_list", "no_volume", "extreme_rates", "degenerate_laws",
+                                  "drift_autoreset", "binding_budget"])
+def test_sparse_kernel_forced(amd, monkeypatch, case):
+    """k_step_implicit_sparse (bracket classification, item list) on shapes the host's hint would not send to it: forced with
+    the engine's scheduling overrides - results may never depend on them"""
+    monkeypatch.setenv("ADCRAFT_FAST_VARIANT", "2")
+    monkeypatch.setenv("ADCRAFT_FAST_TILE_KW", "256")
+    monkeypatch.setenv("ADCRAFT_FAST_TILES_PER_WG", "3")
+    if case == "cfg3_law":
+        planes = H.implicit_params(7, 1024, seed=31, mean_volume=16, cvr=0.1, no_vol_prob=0.5)
+        _run_vs_oracle(amd, 7, 1024, planes, steps=3, budget=1.0e9)
+    elif case == "ragged_tiles":
+        for N, K in ((5, 257), (3, 300), (4, 1), (2, 255)):
+            planes = H.implicit_params(N, K, seed=32 + K, mean_volume=12, cvr=0.5, no_vol_prob=0.3)
+            _run_vs_oracle(amd, N, K, planes, steps=2, budget=1.0e9)
+    elif case == "beyond_the_item_list":      # > 1024 work items per tile: the listed part, then the search
+        planes = H.implicit_params(3, 300, seed=33, mean_volume=128)
+        _run_vs_oracle(amd, 3, 300, planes, steps=2, budget=1.0e9)
+        planes = H.implicit_params(2, 40, seed=34, mean_volume=3000)
+        _run_vs_oracle(amd, 2, 40, planes, steps=2, budget=1.0e9)
+    elif case == "no_volume":
+        planes = H.implicit_params(3, 300, seed=35)
+        planes[0] = 0.0
+        planes[1] = 0.0
+        _run_vs_oracle(amd, 3, 300, planes, steps=2, budget=1.0e9)
+    elif case == "extreme_rates":
+        planes = H.implicit_params(4, 260, seed=36, mean_volume=20)
+        planes[4, 0] = 1.0
+        planes[4, 1] = 0.0
+        planes[4, 2] = np.float32(1e-9)
+        planes[4, 3] = np.float32(1.0 - 1e-7)
+        planes[5, 0] = 0.0
+        planes[5, 1] = 1.0
+        _run_vs_oracle(amd, 4, 260, planes, steps=3, budget=1.0e9, bid_lo=0.01, bid_hi=2.0)
+    elif case == "degenerate_laws":           # brackets that cannot be trusted: everything takes the long way
+        planes = H.implicit_params(4, 260, seed=37, mean_volume=20)
+        planes[3, 0] = 0.0
+        planes[3, 1] *= 50.0
+        planes[3, 2] = np.float32(1e-6)
+        planes[2, 3] = -0.4
+        planes[2, 0, :9] = np.nan
+        planes[3, 0, 9:17] = np.inf
+        planes[4, 0, 17:25] = np.nan
+        _run_vs_oracle(amd, 4, 260, planes, steps=3, budget=1.0e9, bid_lo=0.01, bid_hi=1.5)
+    elif case == "drift_autoreset":
+        planes = H.implicit_params(5, 520, seed=38, mean_volume=16, cvr=0.1, no_vol_prob=0.5)
+        _run_vs_oracle(amd, 5, 520, planes, steps=7, budget=1e9, drift=True, check_params=True, max_days=3, loss_threshold=30.0, auto_reset=True)
+    else:
+        planes = H.implicit_params(6, 300, seed=39, mean_volume=16, cvr=0.3, no_vol_prob=0.4)
+        n = _run_vs_oracle(amd, 6, 300, planes, steps=4, budget=6.0, bid_lo=0.5, bid_hi=1.2)
+        assert n > 0
+
+
+def test_win_brackets_on_the_device(amd):
+    """adc_law.h win_brackets as the GPU evaluates it (v_exp_f32, v_rcp_f32) must enclose the exact intervals too"""
+    import ctypes as C
+    from adcraft_amd import _ffi
+    from tests.test_abi_and_host import _bracket_keywords
+    L = _ffi.lib()
+    rng = np.random.default_rng(41)
+    n = 400_000
+    bid, loc, scale, ctr = _bracket_keywords(rng, n)
+    out = np.zeros((n, 8), np.uint32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.adc_debug_win_brackets_device(0, n, ptr(bid), ptr(loc), ptr(scale), ptr(ctr), ptr(out)) == 0
+    first, amb = C.c_int64(-1), C.c_double(0.0)
+    bad = L.adc_check_win_brackets(n, ptr(bid), ptr(loc), ptr(scale), ptr(ctr), ptr(out), C.byref(first), C.byref(amb))
+    assert bad == 0, (bad, first.value, bid[first.value], loc[first.value], scale[first.value], ctr[first.value], out[first.value])
+    assert amb.value / n / 2.0**32 < 1e-3
+
+
 def test_all_zero_volume_and_extreme_rates(amd):
     planes = H.implicit_params(2, 70, seed=4)
     planes[0] = 0.0

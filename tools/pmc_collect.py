@@ -29,7 +29,7 @@ for name, counters in PASSES.items():
         subprocess.check_call(cmd, stdout=log, stderr=subprocess.STDOUT)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "implicit_fast" in r["Kernel_Name"]:
+            if "k_step_implicit" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 sys.path.insert(0, ".")

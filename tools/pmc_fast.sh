@@ -11,7 +11,7 @@ import csv, glob, collections, sys
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "implicit_fast" in r["Kernel_Name"]:
+        if "k_step_implicit" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:24s} {sum(v) / len(v):.5g}   (n={len(v)})")
