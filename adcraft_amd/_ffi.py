@@ -124,6 +124,7 @@ def lib():
         "adc_engine_profile_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_profile_sample_every": ([vp, C.c_int32], C.c_int),
         "adc_engine_profile_read": ([vp, vp, C.POINTER(i64)], C.c_int),
+        "adc_engine_profile_records": ([vp, C.POINTER(i64)], C.c_int),
         "adc_engine_metrics_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_metrics_reset": ([vp], C.c_int),
         "adc_engine_metrics_read": ([vp, vp, vp], C.c_int),

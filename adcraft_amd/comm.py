@@ -11,6 +11,8 @@ import tempfile
 import time
 
 ID_BYTES = 128
+_bring_ups = 0       # collective bring-ups this process has taken part in (every rank counts alike): part of each rendezvous name,
+                     # so two engines brought up back to back (bench.py: cfg4, then cfg5) can never read each other's files
 
 
 def env_rank_world():
@@ -69,6 +71,13 @@ def exchange_bytes(rank, world_size, make_payload, tag="id", nbytes=ID_BYTES, ti
     return payload
 
 
+def next_bring_up():
+    """sequence number of a collective bring-up (call it once per bring-up, on every rank)"""
+    global _bring_ups
+    _bring_ups += 1
+    return _bring_ups
+
+
 def init_engine_comm(engine, rank=None, world_size=None, timeout=300.0):
     """collective over the job's ranks: gives `engine` its RCCL communicator (no-op for a single rank).
     Returns (rank, world_size)."""
@@ -77,7 +86,7 @@ def init_engine_comm(engine, rank=None, world_size=None, timeout=300.0):
     world_size = w if world_size is None else int(world_size)
     if world_size <= 1:
         return rank, world_size
-    uid = exchange_bytes(rank, world_size, engine.comm_unique_id, "id", ID_BYTES, timeout)
+    uid = exchange_bytes(rank, world_size, engine.comm_unique_id, f"id{next_bring_up()}", ID_BYTES, timeout)
     engine.comm_init(uid, rank, world_size)
     return rank, world_size
 
@@ -93,7 +102,7 @@ class FileReducer:
 
     def __init__(self, rank, world_size, timeout=300.0):
         self.rank, self.world, self.timeout, self.seq = int(rank), int(world_size), timeout, 0
-        self.dir = rendezvous_path("reduce.d")
+        self.dir = rendezvous_path(f"reduce{next_bring_up()}.d")
         if self.world > 1:
             os.makedirs(self.dir, exist_ok=True)
 

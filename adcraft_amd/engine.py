@@ -307,6 +307,12 @@ class StepEngine:
         check(self._lib.adc_engine_profile_read(self._h, ms, C.byref(n)))
         return tuple(ms), n.value
 
+    def profile_records(self):
+        """event records issued since the engine was created (four per bracketed step; none while profiling is off)"""
+        n = C.c_int64()
+        check(self._lib.adc_engine_profile_records(self._h, C.byref(n)))
+        return n.value
+
     def metrics_enable(self, on=True):
         check(self._lib.adc_engine_metrics_enable(self._h, 1 if on else 0))
 

@@ -34,7 +34,6 @@ BYTES_PER_ENV = 26
 MAX_DAYS = 60
 # the three intervals between the engine's HIP events; the IMPLICIT kernels add their metric sums in their own output phase, so
 # the third interval holds no kernel here (what it shows is the cost of recording an event pair)
-PROFILE_EVERY = 8          # steps between event-bracketed steps inside the timed region (fewer for short runs: >= 25 samples)
 KERNEL_NAMES = ("k_step_implicit_fast", "k_tail_or_flag + k_step_exact_rows (step tail)", "(no kernel: event-record overhead)")
 # the reference's own Python loop, unmodified, on this keyword law: measured in the BUILD container (tools/time_reference_python.py,
 # one Xeon core @ 2.1 GHz, stand-ins for the two modules that cannot be imported there) - never on the GPU box, where
@@ -112,10 +111,18 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         eng.step_device()
     red.metric_sums(ideal_k * warmup, ideal_pos_k * warmup)       # also brings the collective path up outside the timed region
     barrier()
-    eng.metrics_reset()
-    every = max(1, min(PROFILE_EVERY, steps // 25))
-    eng.profile_enable(True, every=every)
+    # kernel times: a separate, UNTIMED pass of the same length with HIP events around every step (four event records per step
+    # keep a step's small tail kernels from overlapping the next step's launch: ~16 us of every step) ...
+    eng.profile_enable(True, every=1)
     eng.profile_read()
+    for _ in range(steps):
+        eng.step_device()
+    barrier()
+    kernel_ms, launches = eng.profile_read()
+    eng.profile_enable(False)
+    # ... and the timed region itself records no event at all
+    eng.metrics_reset()
+    records_before = eng.profile_records()
     barrier()
     t0 = time.perf_counter()
     for s in range(steps):
@@ -124,8 +131,7 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
             red.metric_sums(ideal_k * (s + 1), ideal_pos_k * (s + 1))     # the single collective of the path, once per episode
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = eng.profile_read()
-    eng.profile_enable(False)
+    records_in_timed_region = eng.profile_records() - records_before
     profit_c, ideal, ideal_pos, sc = red.metric_sums(ideal_k * steps, ideal_pos_k * steps)
     elapsed = float(red.allreduce([elapsed], op="max")[0])          # the slowest rank's time
     _, ranks_in_comm = eng.comm_info()
@@ -149,9 +155,10 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                      "traffic": notes.get("hbm_bytes_per_launch"),
                      "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else None),
                      "kernel": KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps,
-                     "kernel_ms_method": f"HIP events on the engine's stream around every {every}. step of the timed region (four event "
-                                         "records a step cost ~16 us of throughput; rocprofv3 --kernel-trace --stats of the same "
-                                         "command: profiles/r02_final_rocprof_summary.md)",
+                     "event_records_in_timed_region": int(records_in_timed_region),
+                     "kernel_ms_method": f"HIP events on the engine's stream around every step of a separate, untimed pass of {steps} steps "
+                                         "run between the warm-up and the timed region (same process, same state; the timed region itself "
+                                         "records no event); rocprofv3 --kernel-trace --stats of the same command: profiles/",
                      "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(KERNEL_NAMES, kernel_ms)},
                      "algorithmic_bytes_per_launch": b_alg},
     }
@@ -208,23 +215,29 @@ def host_step(local_rank, steps=120):
 
 
 def rehearse_rank(args, rank, world):
-    """--rehearse: everything around the GPU work, without a GPU (tests/test_distributed_cpu.py): the id hand-over, a
-    reduction, the slowest-rank time, the line"""
+    """--rehearse: everything around the GPU work, without a GPU (tests/test_distributed_cpu.py): TWO bring-ups back to back,
+    as the real N > 1 run has them (cfg4's engine, then cfg5's) - each an id hand-over and a reduction - the slowest-rank
+    time, the line"""
     from adcraft_amd import comm, synthetic
     if args.fail_rank == rank:
+        sys.stderr.write(f"bench.py: rank {rank} fails on request (--fail-rank)\n")
         raise SystemExit(3)
-    uid = comm.exchange_bytes(rank, world, lambda: bytes(range(128)))
-    red = comm.FileReducer(rank, world)
-    seen = red.allreduce(np.eye(world)[rank])
-    elapsed = float(red.allreduce([0.001 * (rank + 1) * args.steps], op="max")[0])
-    red.close()
+    seen, ids = [], []
+    for bring_up in range(2):
+        uid = comm.exchange_bytes(rank, world, lambda: bytes((bring_up + i) % 256 for i in range(128)), tag=f"id{comm.next_bring_up()}")
+        red = comm.FileReducer(rank, world)
+        seen.append(red.allreduce(np.eye(world)[rank] * (bring_up + 1)))
+        elapsed = float(red.allreduce([0.001 * (rank + 1) * args.steps], op="max")[0])
+        red.close()
+        ids.append(uid)
     if rank == 0:
         N, K = synthetic.CONFIGS["cfg4"][:2]
         print(json.dumps({"metric": "env-steps/sec (envs×keywords auctions/s)", "value": None, "unit": "keyword-steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none (rehearsal)",
                           "config": {"workload": f"cfg4: {N} envs x {K} keywords per GPU (not run: --rehearse)"},
-                          "rehearsal": {"ranks_seen": [int(i) for i in np.nonzero(seen)[0]], "id_bytes": len(uid)}}), flush=True)
+                          "rehearsal": {"ranks_seen": [int(i) for i in np.nonzero(seen[0])[0]], "id_bytes": len(ids[0]), "bring_ups": len(ids),
+                                        "ids_distinct": ids[0] != ids[1], "second_reduction": [float(x) for x in seen[1]]}}), flush=True)
 
 
 def run_rank(args):
@@ -279,36 +292,63 @@ def free_port():
 
 
 def launch_ranks(args):
-    """start args.gpus fresh rank processes (this process never touches a GPU), relay rank 0's line"""
+    """start args.gpus fresh rank processes (this process never touches a GPU), relay rank 0's line; a rank that fails - or
+    the job outliving --launch-timeout - ends every rank, and what the failing ranks wrote to stderr is relayed"""
+    import glob
+    import shutil
+    import tempfile
     port = free_port()
-    procs = []
+    job = f"bench{os.getpid()}"
+    logdir = tempfile.mkdtemp(prefix=f"adcraft_{job}_")
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ADCRAFT_JOB_ID=f"bench{os.getpid()}")
+                   MASTER_PORT=str(port), ADCRAFT_JOB_ID=job)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(open(os.path.join(logdir, f"rank{r}.err"), "w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1], text=True))
+
+    def end_job(reason):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        codes = [p.returncode for p in procs]
+        sys.stderr.write(f"bench.py: {reason}; rank exit codes {codes}\n")
+        for r, f in enumerate(errs):
+            f.seek(0)
+            tail = f.read()[-2000:]
+            if tail.strip() and codes[r] not in (0, -9):         # (-9: a rank this launcher ended itself)
+                sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{tail}\n")
+        for leftover in glob.glob(os.path.join(tempfile.gettempdir(), f"adcraft_comm_{port}_{job}.*")):
+            shutil.rmtree(leftover, ignore_errors=True) if os.path.isdir(leftover) else os.remove(leftover)
+        raise SystemExit(1)
+
     # rank 0's line is a few KB: it fits the pipe, so polling the exit codes first cannot deadlock on it
-    while True:
-        codes = [p.poll() for p in procs]
-        if any(c not in (None, 0) for c in codes):          # a rank failed: the others would wait for it forever
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-            for p in procs:
-                p.wait()
-            sys.stderr.write(f"bench.py: rank exit codes {[p.returncode for p in procs]}\n")
-            import glob
-            import shutil
-            import tempfile
-            for leftover in glob.glob(os.path.join(tempfile.gettempdir(), f"adcraft_comm_{port}_bench{os.getpid()}.*")):
-                shutil.rmtree(leftover, ignore_errors=True) if os.path.isdir(leftover) else os.remove(leftover)
-            raise SystemExit(1)
-        if all(c == 0 for c in codes):
-            break
-        time.sleep(0.05)
-    sys.stdout.write(procs[0].stdout.read())
-    sys.stdout.flush()
+    deadline = time.monotonic() + args.launch_timeout
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):          # a rank failed: the others would wait for it forever
+                end_job("a rank failed")
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                end_job(f"no result after --launch-timeout {args.launch_timeout:.0f} s")
+            time.sleep(0.05)
+        sys.stdout.write(procs[0].stdout.read())
+        sys.stdout.flush()
+        for r, f in enumerate(errs):                             # warnings of healthy ranks are not lost either
+            f.seek(0)
+            text = f.read()
+            if text.strip():
+                sys.stderr.write(text if r == 0 else f"[rank {r}] {text}")
+    finally:
+        for f in errs:
+            f.close()
+        shutil.rmtree(logdir, ignore_errors=True)
 
 
 def main():
@@ -323,6 +363,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--rehearse", action="store_true", help="no GPU work: launch, id hand-over and reduction only (CPU test)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds the self-started ranks of --gpus N may take before the job is ended")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)

@@ -261,6 +261,9 @@ int adc_engine_profile_sample_every(adc_engine *e, int32_t every);
 /* kernel_ms_total[3] = summed durations of {fast pass, exact pass + step tail, metric accumulate} over `launches`
  * MEASURED steps since enable / the last read; resets the counters */
 int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, int64_t *launches);
+/* hipEventRecord calls the engine has issued since it was created (four per bracketed step): lets a benchmark show that
+ * its timed region recorded none */
+int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------------------------- */
 /* Envs shard over the GPUs of a node, one process (one engine) per GPU; nothing on the step path communicates.  The

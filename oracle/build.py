@@ -23,7 +23,20 @@ def _stale(out):
     return (not os.path.exists(out)) or os.path.getmtime(out) < os.path.getmtime(SRC)
 
 
+BATTERY_SRC = os.path.join(HERE, "stream_battery.c")
+BATTERY = os.path.join(HERE, "libstream_battery.so")
+
+
+def build_battery(force=False):
+    """the stream-quality battery (stream_battery.c): plain integer code, one build"""
+    if force or not os.path.exists(BATTERY) or os.path.getmtime(BATTERY) < os.path.getmtime(BATTERY_SRC):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp", "-Wall", "-Wextra",
+                               BATTERY_SRC, "-o", BATTERY, "-lm"])
+    return BATTERY
+
+
 def build(force=False):
+    build_battery(force)
     outs = []
     for name, extra in (("libadcraft_oracle.so", []), ("libadcraft_oracle_fma.so", ["-mfma", "-mavx2"])):
         out = os.path.join(HERE, name)

@@ -132,8 +132,16 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["rehearsal"]["ranks_seen"] == [0, 1] and line["rehearsal"]["id_bytes"] == 128
+    # two communicators are brought up back to back (as cfg4 then cfg5 are): each hand-over delivers its own id
+    assert line["rehearsal"]["bring_ups"] == 2 and line["rehearsal"]["ids_distinct"] and line["rehearsal"]["second_reduction"] == [2.0, 2.0]
     assert "cfg4" in line["config"]["workload"]
     # a failing rank fails the launch
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse", "--fail-rank", "1"],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+    assert "rank 1 stderr" in bad.stderr and "fails on request" in bad.stderr          # what the failing rank said is relayed
+    # a job that outlives --launch-timeout is ended, not waited for
+    slow = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse",
+                           "--launch-timeout", "0"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert slow.returncode != 0 and "launch-timeout" in slow.stderr
+    assert not [f for f in os.listdir("/tmp") if f.startswith("adcraft_comm_") and "_bench" in f]          # nothing left behind

@@ -32,7 +32,7 @@ def test_bench_line_contract():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
     assert r["algorithmic_bytes_per_launch"] == 4096 * 256 * 56 + 26 * 4096 and r["launches"] == 6
-    assert r["kernel_ms"] <= d["ms_per_step"] * 1.01           # the kernel runs inside the timed region
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.05           # (measured in the untimed pass of the same length)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["single_thread"]["cores"] == 1 and 0 < c["single_thread"]["value"] <= c["value"] * 1.5
@@ -47,6 +47,17 @@ def test_bench_line_contract():
     assert a["cfg3"]["steps"] >= 50 and a["cfg3"]["roofline"]["algorithmic_bytes_per_launch"] == 16384 * 1024 * 56 + 26 * 16384
     assert a["cfg3"]["value"] == pytest.approx(16384 * 1024 / (a["cfg3"]["ms_per_step"] * 1e-3), rel=1e-6)
     assert a["cfg3"]["roofline"]["frac"] > d["roofline"]["frac"]          # the sparse config is the HBM-heavy one
+
+
+def test_driver_shaped_run_times_a_region_without_event_records():
+    """what the driver runs (--steps 20 --warmup 5): exactly 20 launches in the timed region, no event record among them; the
+    kernel time comes from the separate, untimed, equally long pass and cannot exceed the step time by more than noise"""
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-also")
+    r = d["roofline"]
+    assert d["steps"] == 20 and d["warmup"] == 5
+    assert r["launches_in_timed_region"] == 20 and r["event_records_in_timed_region"] == 0 and r["launches"] == 20
+    assert "untimed pass" in r["kernel_ms_method"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.05
 
 
 def test_bench_other_configs_run():
