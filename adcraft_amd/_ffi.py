@@ -130,6 +130,8 @@ def lib():
         "adc_engine_metrics_read": ([vp, vp, vp], C.c_int),
         "adc_engine_ideal_profit": ([vp, C.c_int, vp, C.c_int, vp], C.c_int),
         "adc_bid_curves_from_samples": ([C.c_int, vp, i32, vp, i32, vp, vp], C.c_int),
+        "adc_engine_metrics_akncp_ncp": ([vp, f64, vp, vp], C.c_int),
+        "adc_engine_outcomes_replay": ([vp, i32, vp, f32, i64, vp, vp, vp, vp, C.POINTER(i64), vp], C.c_int),
         "adc_nth_price_auction": ([C.c_int, f64, vp, i32, i32, i32, i32, C.POINTER(i32), vp, vp], C.c_int),
         "adc_sigmoid": ([f64, f64, f64], f64),
         "adc_clamp": ([f64, f64, f64], f64),
@@ -143,6 +145,7 @@ def lib():
         "adc_auction_word_brackets": ([f32, f32, f32, f32, vp], C.c_int),
         "adc_check_win_brackets": ([i64, vp, vp, vp, vp, vp, vp, vp], i64),
         "adc_debug_win_brackets_device": ([C.c_int, i64, vp, vp, vp, vp, vp], C.c_int),
+        "adc_debug_philox_device": ([C.c_int, i64, vp, vp, vp], C.c_int),
         "adc_comm_get_unique_id": ([vp], C.c_int),
         "adc_engine_comm_init": ([vp, vp, i32, i32], C.c_int),
         "adc_engine_comm_destroy": ([vp], C.c_int),

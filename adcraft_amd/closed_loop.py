@@ -14,10 +14,11 @@ from . import experiment_metrics as em
 
 
 def run_baseline_episode(engine, policy="zero_margin", steps=None, budget=100000.0, default_rpc=1.0, agent_seeds=None,
-                         n_samples=2048, bid_grid=None, curves=True):
+                         n_samples=2048, bid_grid=None, curves=True, per_keyword_sums=True):
     """One episode of `steps` days (default: the engine's max_days) for every env of `engine` (already reset, keywords
     set).  policy: "zero_margin" (NaiveZeroMarginStrategy) or "oracle" (bid the argmax of the expected profit).
-    Returns dict(kw_profit_sum [N, K], ideal_sum [N, K], AKNCP [N], NCP [N])."""
+    Returns dict(kw_profit_sum [N, K], ideal_sum [N, K], AKNCP [N], NCP [N]).  per_keyword_sums=False: only AKNCP and NCP,
+    reduced on the device (the per-env median over the keywords included): 2 N numbers cross the bus, not 3 N K."""
     if policy not in ("zero_margin", "oracle"):
         raise ValueError("policy must be 'zero_margin' or 'oracle'")
     steps = int(engine.max_days if steps is None else steps)
@@ -28,8 +29,11 @@ def run_baseline_episode(engine, policy="zero_margin", steps=None, budget=100000
     if policy == "zero_margin":
         engine.agent_init(default_rpc, agent_seeds)
     engine.run_days(policy, steps, budget)     # agent / ideal profit / step for every day, one host call
-    profit, ideal, ideal_pos = engine.metrics_read_nk()
     n = float(steps)
+    if not per_keyword_sums:
+        akncp, ncp = engine.metrics_akncp_ncp(n)
+        return dict(AKNCP=akncp, NCP=ncp)
+    profit, ideal, ideal_pos = engine.metrics_read_nk()
     with np.errstate(divide="ignore", invalid="ignore"):
         akncp = np.median((profit / n) / (ideal_pos / n), axis=1)             # experiment_metrics.py:64-76
     den = ideal.sum(axis=1)

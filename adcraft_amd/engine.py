@@ -229,6 +229,24 @@ class StepEngine:
         _check_overflow(self._overflow)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
+    def outcomes_replay(self, env, bids_k, budget):
+        """the paid clicks of env `env`'s LAST step, one by one, in the reference's order (adc_engine_outcomes_replay): dict of
+        keyword, timestep, cost (dollars), revenue (dollars, -1 = no conversion) and share_volume [K].  Call before the next step."""
+        K = self.num_keywords
+        bids = np.ascontiguousarray(bids_k, dtype=np.float32).reshape(K)
+        share = np.zeros(K, np.int32)
+        n = C.c_int64(0)
+        cap = 4096
+        while True:
+            kw, ts = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+            cost, rev = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+            check(self._lib.adc_engine_outcomes_replay(self._h, int(env), bids.ctypes.data, float(budget), cap, kw.ctypes.data, ts.ctypes.data,
+                                                       cost.ctypes.data, rev.ctypes.data, C.byref(n), share.ctypes.data))
+            if n.value <= cap:
+                m = n.value
+                return dict(keyword=kw[:m], timestep=ts[:m], cost=cost[:m], revenue=rev[:m], share_volume=share)
+            cap = int(n.value)
+
     def step_flat(self, flat_actions):
         """FlatArrayWrapper-layout step: actions float32 [N, K+1] = [budget, bids...] -> (flat_obs [N, 5K+2], reward,
         terminated, truncated); the returned arrays are views of page-locked buffers, valid until the next step"""
@@ -443,6 +461,12 @@ class StepEngine:
         if graph is not None:
             check(self._lib.adc_engine_day_graph_enable(self._h, 1 if graph else 0))
         check(self._lib.adc_engine_run_days(self._h, self.POLICIES[policy], int(days), float(budget)))
+
+    def metrics_akncp_ncp(self, days):
+        """(AKNCP [N], NCP [N]) of the running episode, reduced on the device (per-env median over the keywords in LDS)"""
+        a, b = np.zeros(self.num_envs, np.float64), np.zeros(self.num_envs, np.float64)
+        check(self._lib.adc_engine_metrics_akncp_ncp(self._h, float(days), a.ctypes.data, b.ctypes.data))
+        return a, b
 
     def metrics_read_nk(self, ideal=True):
         """per (env, keyword) sums: profit in dollars, and (if ideal) the ideal sum and the ideal sum with <= 0 -> 1"""

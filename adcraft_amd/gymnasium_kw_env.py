@@ -12,11 +12,14 @@ What differs from the reference, on purpose (DESIGN.md "quirks"):
     stream - numpy PCG64 interleaved with an UNSEEDED Rust thread_rng - is not reproducible even by
     the reference); keyword parameters generated at reset(seed) ARE bit-identical to the reference's;
   * bids are canonicalised to integer cents (numpy-1.x promotion semantics, SURVEY B-9);
-  * info["bidding_outcomes"] is a lazily formatted per-keyword summary (the per-click lists of
-    src/lib.rs:251-275 never exist in a fused kernel);
+  * info["bidding_outcomes"] is formatted only when somebody reads it: the per-click lists of src/lib.rs:251-275 never
+    exist in a fused kernel, but every variate is addressed by what it is for, so they are regenerated exactly by a
+    read-only second walk of the step (adc_engine_outcomes_replay) - at the latest when the next step begins, and only
+    if the info dict is still alive then;
   * only updater_mask None or all-True is supported (the only masks the reference's configs use; a
     partial mask mis-aligns coefficients in the reference, gymnasium_kw_env.py:136-144).
 """
+import weakref
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -62,7 +65,12 @@ class _Lazy:
     def __str__(self):
         if self._s is None:
             self._s = self._fn()
+            self._fn = None
         return self._s
+
+    def settle(self):
+        """format now (the engine is about to move on)"""
+        str(self)
 
     __repr__ = __str__
 
@@ -167,6 +175,7 @@ class BiddingSimulation(_EnvBase):
         """gymnasium_kw_env.py:114-158, on the device (engine drift stream)"""
         if self.updater_mask is None:
             return
+        self._settle_outcomes()
         assert len(self.updater_mask) == self.num_keywords
         assert self._engine is not None, "reset required, need to generate keywords to bid on"
         self._engine.update_keywords()
@@ -208,6 +217,7 @@ class BiddingSimulation(_EnvBase):
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        self._settle_outcomes()
         super().reset(seed=seed)
         resample = seed is not None or not self._have_keywords          # gymnasium_kw_env.py:303
         self._ensure_engine(seed)
@@ -251,6 +261,7 @@ class BiddingSimulation(_EnvBase):
         bids64 = np.asarray(bid_array, dtype=np.float64).reshape(self.num_keywords)
         rounded = np.round(np.maximum(bids64, 0.01), 2)                                      # :215 (f64: B-9)
         bids = rounded.tolist()
+        self._settle_outcomes()
         out = self._engine.step(rounded.astype(np.float32)[None, :],
                                 np.float32(np.asarray(self.budget, dtype=np.float64).reshape(-1)[0]), copy=False)
         profits = float(out["reward"][0])
@@ -270,9 +281,12 @@ class BiddingSimulation(_EnvBase):
         if self._drift_on():
             self._params_dirty = True            # update_keywords() ran on the device (:246)
         snap = dict(observations)            # (the arrays are this step's own copies; formatted only if somebody looks)
+        budget_used = float(np.float32(np.asarray(self.budget, dtype=np.float64).reshape(-1)[0]))
+        outcomes = _Lazy(lambda: self._repr_outcomes(bids, snap, self._engine.outcomes_replay(0, rounded.astype(np.float32), budget_used)))
+        self._pending_outcomes = weakref.ref(outcomes)        # settled when the next step begins, if anybody still holds the info
         info = {
             "bids": bids,
-            "bidding_outcomes": _Lazy(lambda: self._repr_outcomes(bids, snap)),
+            "bidding_outcomes": outcomes,
             "keyword_params": _Lazy(lambda: utils.repr_all_params(self.keyword_params)),
         }
         if self.render_mode == "ansi":                                                       # :253-260
@@ -288,15 +302,53 @@ class BiddingSimulation(_EnvBase):
                                    + f"but our cumulative loss was ({self.cumulative_profit:.2f})")
         return observations, reward, terminated, truncated, info
 
+    def _settle_outcomes(self):
+        """the previous step's info["bidding_outcomes"] can only be regenerated while the engine still stands where that step
+        left it: if the caller kept the info dict, format it now"""
+        ref = getattr(self, "_pending_outcomes", None)
+        self._pending_outcomes = None
+        lazy = ref() if ref is not None else None
+        if lazy is not None:
+            lazy.settle()
+
     @staticmethod
-    def _repr_outcomes(bids, obs):
+    def _repr_outcomes(bids, obs, clicks):
+        """src/lib.rs:251-275 (repr_outcomes_py) on the regenerated per-click lists: `{}` of an f64 prints 1 for 1.0, `{:?}`
+        prints 1.0; 'profit' adds the sub-timesteps' (revenues - costs) in order, as combine_outcomes does
+        (bidding_simulation.py:117-119,127-133)"""
+        def disp(x):
+            x = float(x)
+            return str(int(x)) if x == int(x) and abs(x) < 1e16 else repr(x)
+
+        K = len(bids)
         rows = []
+        by_kw = [[] for _ in range(K)]
+        for i in range(len(clicks["keyword"])):
+            by_kw[int(clicks["keyword"][i])].append(i)
         for k, b in enumerate(bids):
-            rows.append("{" + f"'bid': {b}, 'impressions': {int(obs['impressions'][k])}, "
-                        f"'buyside_clicks': {int(obs['buyside_clicks'][k])}, 'cost': {float(obs['cost'][k])}, "
-                        f"'sellside_conversions': {int(obs['sellside_conversions'][k])}, "
-                        f"'revenue': {float(obs['revenue'][k])}, "
-                        f"'profit': {float(obs['revenue'][k]) - float(obs['cost'][k])}" + "}")
+            idx = by_kw[k]
+            costs = [float(clicks["cost"][i]) for i in idx]
+            rpc = [max(float(clicks["revenue"][i]), 0.0) for i in idx]
+            revenues = [float(clicks["revenue"][i]) for i in idx if clicks["revenue"][i] >= 0]
+            profit, t_prev, cell_r, cell_c = 0.0, None, 0.0, 0.0
+            for i in idx:                                   # per sub-timestep: sum(revenues) - sum(costs), then added up
+                t = int(clicks["timestep"][i])
+                if t != t_prev and t_prev is not None:
+                    profit += cell_r - cell_c
+                    cell_r = cell_c = 0.0
+                t_prev = t
+                cell_c += float(clicks["cost"][i])
+                if clicks["revenue"][i] >= 0:
+                    cell_r += float(clicks["revenue"][i])
+            if t_prev is not None:
+                profit += cell_r - cell_c
+            imp = int(obs["impressions"][k])
+            vol = int(clicks["share_volume"][k])
+            share = imp / vol if vol > 0 else 0.0
+            rows.append("{" + f"'bid': {disp(b)}, 'impressions': {imp}, 'impression_share': {disp(share)}, "
+                        f"'buyside_clicks': {int(obs['buyside_clicks'][k])}, 'costs': {costs!r}, "
+                        f"'sellside_conversions': {int(obs['sellside_conversions'][k])}, 'revenues': {revenues!r}, "
+                        f"'revenues_per_cost': {rpc!r}, 'profit': {disp(profit)}" + "}")
         return "[" + ", ".join(rows) + "]"
 
     def render(self) -> Optional[str]:
@@ -304,6 +356,7 @@ class BiddingSimulation(_EnvBase):
             return self._current_text
 
     def close(self):
+        self._settle_outcomes()
         if self._engine is not None:
             self._engine.close()
             self._engine = None

@@ -352,6 +352,23 @@ int adc_engine_day_graph_enable(adc_engine *e, int enabled);
 /* per (env, keyword) metric sums to host (any pointer may be NULL): profit in cents, ideal, ideal with <= 0 -> 1;
  * per-env AKNCP = median_k(profit / ideal_pos), NCP = sum profit / sum ideal (experiment_metrics.py:64-83) */
 int adc_engine_metrics_read_nk(adc_engine *e, int64_t *profit_cents_nk, double *ideal_sum_nk, double *ideal_pos_sum_nk);
+/* the same two metrics reduced on the device: akncp_n[N] = median over the keywords of (profit / days) / (ideal_pos / days) (a
+ * bitonic sort per env in LDS; numpy's median convention), ncp_n[N]; 2 N doubles cross the bus instead of 3 N K.
+ * num_keywords <= 4096. */
+int adc_engine_metrics_akncp_ncp(adc_engine *e, double days, double *akncp_n, double *ncp_n);
+
+/* ---- info["bidding_outcomes"] on demand (src/lib.rs:251-275, adcraft/gymnasium_kw_env.py:247-251) -------------------- */
+/* The fused step kernels keep per-keyword totals, not the per-click lists the reference formats ('costs', 'revenues',
+ * 'revenues_per_cost').  Every variate is addressed by (env key; index, stage, keyword, tick), so those lists can be
+ * regenerated exactly, only when somebody reads them: this call walks env `env`'s LAST step once more, read-only, in the
+ * reference's order (sub-timestep, keyword, auction; the budget walk in its floating point) and lists the paid clicks:
+ * keyword[i], timestep[i], cost[i] (dollars), revenue[i] (dollars; -1 = the click did not convert).  *count = paid clicks
+ * of the step (may exceed capacity: then only `capacity` are stored).  share_volume_k[K] (optional) = per keyword, the
+ * auctions of the sub-timesteps that had an impression - the denominator combine_outcomes ends up with for
+ * 'impression_share' (bidding_simulation.py:130-146).  Call it before the next step of the engine; `bids_k` and `budget`
+ * are the step's action for this env.  ADC_ESTATE after a tape replay or before any step. */
+int adc_engine_outcomes_replay(adc_engine *e, int32_t env, const float *bids_k, float budget, int64_t capacity, int32_t *keyword,
+                               int32_t *timestep, double *cost, double *revenue, int64_t *count, int32_t *share_volume_k);
 
 /* ---- standalone auction clearing (adcraft/synthetic_kw_helpers.py:116-180) ------------------------ */
 /* other_bids: host double [n_auctions][n_bidders]; placements/costs: host, capacity n_auctions.
@@ -384,6 +401,9 @@ int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, floa
 int adc_auction_word_brackets(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out8);
 int64_t adc_check_win_brackets(int64_t n, const float *bid, const float *cost_loc, const float *cost_scale, const float *buyside_ctr,
                                const uint32_t *brackets8, int64_t *first_bad, double *ambiguous_words);
+/* diagnostic: the stream's generator (Philox4x32, the stream's round count) evaluated on the device for n counters ctr4[n][4]
+ * and keys key2[n][2] -> out4[n][4]; tests compare it with the CPU battery's generator (oracle/stream_battery.c) */
+int adc_debug_philox_device(int device_id, int64_t n, const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);
 int adc_debug_win_brackets_device(int device_id, int64_t n, const float *bid, const float *cost_loc, const float *cost_scale,
                                   const float *buyside_ctr, uint32_t *out8);
 

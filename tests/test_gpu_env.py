@@ -45,6 +45,58 @@ def test_reference_env_tests(pkg):
     env.close()
 
 
+@pytest.mark.parametrize("implicit,budget", [(True, 1.0e6), (True, 3.0), (False, 1.0e6), (False, 40.0)])
+def test_bidding_outcomes_lists_every_click_on_demand(pkg, implicit, budget):
+    """info["bidding_outcomes"] (src/lib.rs:251-275): the per-click lists are regenerated from the stream when the string is
+    read - every cost and revenue of the step, consistent with the step's observations to the cent, under binding and
+    non-binding budgets, for both keyword models; and a string read only after the NEXT step is still the first step's."""
+    import ast
+
+    def make():
+        kw = dict(keyword_config=_cfg(40, 0.5), num_keywords=24) if implicit else dict(num_keywords=24)
+        e = pkg.BiddingSimulation(budget=budget, **kw)
+        e.reset(seed=5)
+        return e
+
+    env, twin = make(), make()
+    rng = np.random.default_rng(2)
+    bound = False
+    kept = []
+    for day in range(3):
+        act = {"keyword_bids": rng.uniform(0.4, 1.6, 24).round(2), "budget": np.array([budget])}
+        obs, reward, *_, info = env.step(act)
+        obs2, reward2, *_, info2 = twin.step(act)
+        text = str(info["bidding_outcomes"])                 # read at once
+        kept.append((info2, text))                           # the twin's is read after its NEXT step (below)
+        rows = ast.literal_eval(text)
+        assert len(rows) == 24 and list(rows[0]) == ["bid", "impressions", "impression_share", "buyside_clicks", "costs", "sellside_conversions",
+                                                       "revenues", "revenues_per_cost", "profit"]
+        total = 0.0
+        for k, r in enumerate(rows):
+            assert r["bid"] == pytest.approx(float(act["keyword_bids"][k]))
+            assert r["impressions"] == obs["impressions"][k] and r["buyside_clicks"] == obs["buyside_clicks"][k] == len(r["costs"])
+            assert r["sellside_conversions"] == obs["sellside_conversions"][k] == len(r["revenues"])
+            assert len(r["revenues_per_cost"]) == len(r["costs"]) and [x for x in r["revenues_per_cost"] if x != 0.0] == r["revenues"]
+            assert 0.0 <= r["impression_share"] <= 1.0 and (r["impression_share"] > 0) == (r["impressions"] > 0)
+            if implicit:     # whole cents: the lists add up to the observation exactly
+                assert round(sum(r["costs"]) * 100) == round(float(obs["cost"][k]) * 100)
+                assert all(abs(c * 100 - round(c * 100)) < 1e-9 for c in r["costs"])
+            else:
+                assert sum(r["costs"]) == pytest.approx(float(obs["cost"][k]), rel=1e-6, abs=1e-6)
+            assert round(sum(r["revenues"]) * 100) == round(float(obs["revenue"][k]) * 100)
+            assert r["profit"] == pytest.approx(sum(r["revenues"]) - sum(r["costs"]), abs=1e-9)
+            total += r["profit"]
+        assert total == pytest.approx(reward, abs=1e-6)
+        spend = sum(sum(r["costs"]) for r in rows)
+        assert spend <= budget + 1e-9
+        bound = bound or spend > budget - 2.0
+    assert bound == (budget < 1e5)                           # the small budgets really bound
+    for (late_info, text_then) in kept:                      # settled when the twin's next step began (the dict was alive)
+        assert str(late_info["bidding_outcomes"]) == text_then
+    env.close()
+    twin.close()
+
+
 def test_reset_seed_reproduces_reference_keywords(pkg, golden):
     kat = golden("g2_keyword_params.json")["notebook_kat"]
     env = pkg.BiddingSimulation(keyword_config=_cfg(100, 0.3), num_keywords=30)

@@ -108,6 +108,25 @@ def test_sparse_kernel_forced(amd, monkeypatch, case):
         assert n > 0
 
 
+def test_device_philox_is_the_batterys_philox_on_the_production_layout(amd):
+    """the generator the stream battery tested on the CPU (oracle/stream_battery.c) is the one the GPU runs: 2^20 counters laid
+    out as the kernels address them (index, stage, keyword, tick; env keys), word for word"""
+    import ctypes as C
+    from adcraft_amd import _ffi
+    from tests.test_stream_quality import battery
+    L, B = _ffi.lib(), battery()
+    rng = np.random.default_rng(8)
+    n = 1 << 20
+    ctr = np.stack([rng.integers(0, 1 << 18, n), rng.choice([0, 1, 2, 7], n), rng.integers(0, 4096, n), rng.integers(0, 1 << 16, n)], axis=1).astype(np.uint32)
+    key = rng.integers(0, 2**32, (n, 2), dtype=np.uint64).astype(np.uint32)
+    ctr[: n // 2, 0] = np.arange(n // 2) % 4096          # runs of neighbouring counters as well
+    got = np.zeros((n, 4), np.uint32)
+    exp = np.zeros((n, 4), np.uint32)
+    assert L.adc_debug_philox_device(0, n, ctr.ctypes.data_as(C.c_void_p), key.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p)) == 0
+    B.bat_philox(ctr.ctypes.data, key.ctypes.data, n, 7, exp.ctypes.data)
+    assert np.array_equal(got, exp)
+
+
 def test_win_brackets_on_the_device(amd):
     """adc_law.h win_brackets as the GPU evaluates it (v_exp_f32, v_rcp_f32) must enclose the exact intervals too"""
     import ctypes as C
@@ -809,6 +828,16 @@ def test_step_outcome_distributions_match_the_reference(amd, golden):
             se = np.sqrt(np.array(sc["var"][name]) / n_ref + x.var(axis=0, ddof=1) / n_eng)
             z = (x.mean(axis=0) - np.array(sc["mean"][name])) / np.maximum(se, 1e-9)
             assert np.abs(z).max() < 5.0, (sc["name"], name, z.tolist())
+            # ... and the per-keyword VARIANCES (a stream whose neighbouring counters were correlated would keep the means and
+            # change the spread of a day's sums): log-ratio of the two sample variances, its standard error from the
+            # engine's own fourth moment (kurtosis k: var(s^2) ~ s^4 (k - 1) / n)
+            v_ref, v_eng = np.array(sc["var"][name]), x.var(axis=0, ddof=1)
+            ok = (v_ref > 0) & (v_eng > 0)
+            d = x - x.mean(axis=0)
+            kurt = np.where(ok, (d**4).mean(axis=0) / np.maximum(d.var(axis=0), 1e-30) ** 2, 3.0)
+            se_log = np.sqrt(np.maximum(kurt - 1.0, 0.5) * (1.0 / n_eng + 1.0 / n_ref))
+            zv = np.where(ok, np.log(np.maximum(v_eng, 1e-30) / np.maximum(v_ref, 1e-30)) / se_log, 0.0)
+            assert np.abs(zv).max() < 5.0, (sc["name"], name, "variance", zv.tolist())
         r = np.concatenate(acc["reward"])
         z = (r.mean() - sc["reward_mean"]) / np.sqrt(sc["reward_var"] / n_ref + r.var(ddof=1) / n_eng)
         assert abs(z) < 5.0, (sc["name"], "reward", z)

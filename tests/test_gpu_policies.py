@@ -139,6 +139,11 @@ def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
             if fused:
                 r = run_baseline_episode(e, policy, steps=steps, budget=100000.0, default_rpc=1.0, agent_seeds=np.arange(N, dtype=np.uint64))
                 runs.append((r["AKNCP"], r["NCP"]))
+                # the same two metrics reduced on the device (per-env median over the keywords in LDS): the median is the
+                # host's bit for bit (same operations, a sort instead of a partition), NCP to the last bits of the sum order
+                a_dev, n_dev = e.metrics_akncp_ncp(steps)
+                assert np.array_equal(a_dev, r["AKNCP"]), policy
+                assert np.allclose(n_dev, r["NCP"], rtol=1e-12, atol=0), policy
             else:
                 e.bid_curves_build(2048)
                 if policy == "zero_margin":
@@ -162,6 +167,22 @@ def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
         assert np.allclose(runs[0][1], runs[1][1], rtol=1e-5, atol=1e-7), policy
     # the oracle bidder earns about the ideal (NCP near 1), the ramping agent less in 15 days
     assert 0.6 < np.median(runs[0][1]) < 1.4
+
+
+@pytest.mark.parametrize("K", [1, 2, 33, 64, 1000, 4096])
+def test_device_median_matches_numpy_for_odd_even_and_padded_keyword_counts(amd, K):
+    from adcraft_amd.closed_loop import run_baseline_episode
+    N, steps = 3, 3
+    planes = H.implicit_params(N, K, seed=94 + K, mean_volume=6, cvr=0.6, no_vol_prob=0.3)
+    e = amd.StepEngine(N, K, seed=31, max_days=steps)
+    e.set_all_params(planes)
+    e.reset()
+    r = run_baseline_episode(e, "oracle", steps=steps, budget=100000.0, n_samples=256)
+    a_dev, n_dev = e.metrics_akncp_ncp(steps)
+    assert np.array_equal(a_dev, r["AKNCP"]) and np.allclose(n_dev, r["NCP"], rtol=1e-12, atol=0)
+    r2 = run_baseline_episode(e, "oracle", steps=steps, budget=100000.0, n_samples=256, per_keyword_sums=False)      # a second episode: device-only
+    assert set(r2) == {"AKNCP", "NCP"} and r2["AKNCP"].shape == (N,)
+    e.close()
 
 
 @pytest.mark.parametrize("model", [0, 1])
