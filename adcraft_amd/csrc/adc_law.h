@@ -686,6 +686,21 @@ ADC_HD float cents_to_dollars_f32(long long cents)
     return (float)cents / 100.0f;
 }
 
+// the same for an amount known to be non-negative (a keyword-day's spend or revenue): no sign handling
+ADC_HD float cents_to_dollars_f32_nonneg(unsigned long long cents)
+{
+    if (cents < 16777216ull) {
+        unsigned int lo = (unsigned int)cents;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(lo));       // (opaque: knowing the high half to be zero here, hipcc otherwise converts the 64-bit value - 8 instructions for 1)
+#endif
+        const float a = (float)lo;
+        const float q0 = a * 0.01f;
+        return fma32(fma32(-q0, 100.0f, a), 0.01f, q0);
+    }
+    return (float)cents / 100.0f;
+}
+
 ADC_HD float clamp01(float v) { v = v > 0.0f ? v : 0.0f; return v < 1.0f ? v : 1.0f; }
 
 ADC_HD float threshold_sigmoid_f32(float bid, float thresh, float intercept, float slope)
