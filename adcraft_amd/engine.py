@@ -367,6 +367,16 @@ class StepEngine:
         check(self._lib.adc_engine_bid_curves_fetch(self._h, ir.ctypes.data, cpc.ctypes.data))
         return ir, cpc
 
+    def bid_curves_contenders(self):
+        """(count [N, K] (65535 = the whole grid), grid indices [N, K, cap], margin intervals [N, K, cap, 2]) of the curve points
+        the per-step ideal chooses from"""
+        cap = C.c_int32(0)
+        check(self._lib.adc_engine_bid_curves_contenders(self._h, None, None, C.byref(cap)))
+        n = np.zeros((self.num_envs, self.num_keywords), np.uint16)
+        ent = np.zeros((self.num_envs, self.num_keywords, cap.value, 6), np.uint32)
+        check(self._lib.adc_engine_bid_curves_contenders(self._h, n.ctypes.data, ent.ctypes.data, C.byref(cap)))
+        return n, ent[..., 4].astype(np.int32), ent[..., 0:2].copy().view(np.float32)
+
     def ideal_step(self, fetch=True):
         """get_max_expected_bid_profits for the current parameters against the cached curves; with metrics enabled
         the ideal is also accumulated.  Returns (ideal [N, K] dollars, argmax index [N, K]) or None if not fetch."""

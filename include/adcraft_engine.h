@@ -317,6 +317,11 @@ int adc_engine_bid_curves_fetch(adc_engine *e, double *impression_rate_host, dou
  * curves: max expected profit and its argmax over the grid, per keyword; host outputs may be NULL.  With metrics
  * enabled the value is also added to the per-keyword ideal sums (raw, and with <= 0 replaced by 1 as compute_AKNCP
  * does, :71-75). */
+/* diagnostic: per keyword, the grid points that can be the argmax of the expected profit for SOME margin sctr x rev_mean, each
+ * with the margin interval on which it can (found once per adc_engine_bid_curves_build; adc_engine_ideal_step evaluates only
+ * the few whose interval holds the day's margin): n_nk[N*K] (0xFFFF: the whole grid is evaluated), entries_nkc6[N*K][*cap][6]
+ * = {interval lo, hi (float32 bits), curve point (2 words), grid index, 0}, ascending grid indices */
+int adc_engine_bid_curves_contenders(adc_engine *e, uint16_t *n_nk, uint32_t *entries_nkc6, int32_t *cap);
 int adc_engine_ideal_step(adc_engine *e, double *ideal_host_nk, int32_t *best_index_host_nk);
 /* run_oracle_agent: next action := bid_grid[argmax] of the last adc_engine_ideal_step, budget as given */
 int adc_engine_policy_oracle(adc_engine *e, float budget);

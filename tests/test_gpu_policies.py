@@ -124,6 +124,50 @@ def test_ideal_step_is_the_reference_formula_on_the_cached_curves(amd, golden):
     e.close()
 
 
+@pytest.mark.parametrize("case", ["notebook", "few_samples", "coarse_grid", "fine_grid", "extremes"])
+def test_contender_lists_give_the_full_scans_ideal_bit_for_bit(amd, monkeypatch, case):
+    """the per-step ideal evaluated on the contender grid points only (k_curve_contenders + k_ideal_from_contenders) against
+    the same engine evaluating the WHOLE grid (ADCRAFT_IDEAL_FULL_SCAN=1, k_ideal_from_curves - itself pinned to the
+    reference's formula above): value and first argmax identical for every keyword on every day of a strongly drifting episode"""
+    N, K, days = 24, 160, 12
+    n_samples, grid = 2048, None
+    planes = H.implicit_params(N, K, seed=96, mean_volume=30, cvr=0.6)
+    if case == "few_samples":
+        n_samples = 24                                    # long runs of identical lines, many exact ties
+    elif case == "coarse_grid":
+        grid = np.arange(0.05, 2.0, 0.05)
+    elif case == "fine_grid":
+        grid = np.arange(0.002, 2.5, 0.002)               # 1249 points: the stack does not fit -> whole grid, still identical
+    elif case == "extremes":
+        planes[5, 0] = 0.0                                # no conversions: every profit <= 0 -> index 0
+        planes[5, 1] = 1.0
+        planes[6, 2] = 2.0e6                              # margin beyond kMarginMax -> whole grid
+        planes[6, 3] = 1e-6
+        planes[4, 4] = 0.0                                # no clicks
+        planes[0, 5] = 0.0                                # no volume
+        planes[6, 6] = np.nan
+        planes[3, 7] = 1e-4                               # competitor bids all equal: two distinct lines
+    runs = []
+    for full in ("1", "0"):
+        monkeypatch.setenv("ADCRAFT_IDEAL_FULL_SCAN", full)
+        e = amd.StepEngine(N, K, seed=37, drift_enabled=True, drift=(0.3, 0.3, 0.5), max_days=1 << 20, loss_threshold=1e12)
+        e.set_all_params(planes)
+        e.reset()
+        e.bid_curves_build(n_samples, grid)
+        e.sample_actions(0.3, 1.0, 1e9)
+        out = []
+        for _ in range(days):
+            ideal, best = e.ideal_step()
+            out.append((ideal.copy(), best.copy()))
+            e.step_device()
+        runs.append(out)
+        e.close()
+    for (i_full, b_full), (i_fast, b_fast) in zip(*runs):
+        assert np.array_equal(i_full, i_fast, equal_nan=True)
+        assert np.array_equal(b_full, b_fast)
+    assert len({tuple(b.ravel()) for _, b in runs[0]}) > 1 or case == "extremes"      # the argmax really moved with the drift
+
+
 def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
     """run_baseline_episode (everything device-resident) vs the same loop done the notebooks' way: fetch every
     observation, stack kw_profits / ideal_profits, compute_AKNCP / compute_NCP (restatements pinned by G5)"""
