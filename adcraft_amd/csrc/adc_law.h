@@ -35,8 +35,9 @@ namespace adc {
 //           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
-// GENERAL (the reference's default ImplicitKeyword): call (64 t + b/4, ST_GBIDDERS) word b%4 = participation coin of bidder b in
-//           sub-timestep t; call (j, ST_GBID | (b/4) << 8) word b%4 = the bid of bidder b in auction j;
+// GENERAL (the reference's default ImplicitKeyword; stream revision 3 for this model): call (64 t + b/4, ST_GBIDDERS) word b%4 =
+//           participation coin of bidder b in sub-timestep t; call (j, ST_GBID) = the exponential spacings of the TOP bids of
+//           auction j, highest first (top_laplace_bids: order statistics instead of one draw per bidder);
 //           call (j, ST_GCLICK) = {click, conversion, revenue} words of auction j.
 enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8, ST_AGENT = 9,
                         ST_GBIDDERS = 10, ST_GBID = 11, ST_GCLICK = 12 };
@@ -727,6 +728,55 @@ ADC_HD float synthetic_bid(uint32_t w, float lo, float hi)
 {
     const float b = fma32(hi - lo, unit_closed24(w), lo);
     return __builtin_rintf(b * 100.0f) / 100.0f;
+}
+
+// ---- IMPLICIT_GENERAL (the reference's default ImplicitKeyword), stream revision 3: the top bids as ORDER STATISTICS --------
+// An auction of B bidders is cleared against its top (num_winners + 2) competitor bids only (synthetic_kw_helpers.py:152-177).
+// Instead of drawing all B Laplace(loc, |scale|) bids (rng.laplace, synthetic_kw_classes.py:681-686: ~18 draws per auction at
+// the default pool) and keeping the top few, the top k = min(B, top) are drawn directly, in descending order, from ONE call:
+// with E_i ~ Exp(1) independent, t_1 = E_1 / B, t_2 = t_1 + E_2 / (B - 1), ... are -ln of the top uniform order statistics
+// (Renyi), and the Laplace quantile at p = exp(-t) is loc + s (ln 2 - t) for p <= 1/2, loc - s ln(2 (1 - p)) above.  Same
+// joint law of the top k as sorting B draws (tests/test_oracle_scalar.py checks it against numpy); float32 built from the
+// deterministic log / exp above, so the oracle reproduces every bit.  Returns k; out[0] >= out[1] >= ...
+ADC_HD int top_laplace_bids(const U4 &w, int B, int top, float loc, float scale, float out[4])
+{
+    const int k = B < top ? B : top;
+    const float s = __builtin_fabsf(scale);
+    float t = 0.0f;
+    for (int i = 0; i < k && i < 4; ++i) {
+        const uint32_t word = i == 0 ? w.x : i == 1 ? w.y : i == 2 ? w.z : w.w;
+        const float e = -det_log(unit_open23(word));                 // Exp(1)
+        t = t + e / (float)(B - i);
+        float z;                                                     // the standard Laplace quantile at exp(-t)
+        if (t >= 0.693147182464599609375f) z = 0.693147182464599609375f - t;
+        else {
+            float q = 1.0f - det_exp(-t);
+            q = q > 5.9604644775390625e-08f ? q : 5.9604644775390625e-08f;
+            z = -det_log(q + q);
+        }
+        out[i] = fma32(s, z, loc);
+    }
+    return k;
+}
+
+// nth_price_auction(bid, other_bids, n = 2, num_winners = w) (synthetic_kw_helpers.py:116-180) decided from the top w competitor
+// bids alone.  The reference sorts the top (w + 2) bids - zero bids standing in for missing bidders (:156-161) - and wins iff at
+// least 3 of them are below the bid, i.e. iff the w-th highest is; the price sorted[index - 1] is the highest of them if even
+// that one is below the bid, the w-th highest otherwise.  Nothing below the w-th highest matters, so only min(B, w) order
+// statistics are drawn (a prefix of what the oracle draws for its literal sort: same values).  w in {1, 2}.
+ADC_HD bool clear_general_auction(const U4 &w4, int B, int num_winners, float loc, float scale, double bid_d, float &price)
+{
+    float xs[4];
+    const int nb = top_laplace_bids(w4, B, num_winners, loc, scale, xs);
+    float h1 = -3.0e38f, h2 = -3.0e38f;                  // highest, second highest of bids and stand-in zeros
+    for (int h = 0; h < nb; ++h) { const float x = xs[h]; if (x > h1) { h2 = h1; h1 = x; } else if (x > h2) h2 = x; }
+    int zeros = num_winners + 2 - B;
+    zeros = zeros < 2 ? zeros : 2;
+    for (int z = 0; z < zeros; ++z) { if (0.0f > h1) { h2 = h1; h1 = 0.0f; } else if (0.0f > h2) h2 = 0.0f; }
+    const float need = num_winners == 1 ? h1 : h2;
+    if (!((double)need < bid_d)) return false;           // :167-170 (searchsorted left: a tie loses)
+    price = (double)h1 < bid_d ? h1 : need;              // :173-175
+    return true;
 }
 
 // ---- keyword-set generation on the device (law of sample_implicit_keywords_from_quantile_dfs,

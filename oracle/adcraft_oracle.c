@@ -50,9 +50,9 @@ enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_ST
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
 enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8,
        ST_AGENT = 9, ST_GBIDDERS = 10, ST_GBID = 11, ST_GCLICK = 12 };
-/* IMPLICIT_GENERAL (the reference's default ImplicitKeyword): call (64 t + b/4, ST_GBIDDERS) word b%4 = participation coin of
- * bidder b in sub-timestep t; call (j, ST_GBID | (b/4) << 8) word b%4 = the bid of bidder b in auction j; call (j, ST_GCLICK) =
- * {click, conversion, revenue} words of auction j. */
+/* IMPLICIT_GENERAL (the reference's default ImplicitKeyword; stream revision 3 for this model): call (64 t + b/4, ST_GBIDDERS)
+ * word b%4 = participation coin of bidder b in sub-timestep t; call (j, ST_GBID) = the exponential spacings of the top bids of
+ * auction j, highest first (orc_top_laplace_bids); call (j, ST_GCLICK) = {click, conversion, revenue} words of auction j. */
 /* Stream layout (revision 2): call (0, ST_VOL, k/4) holds the volume words of keywords 4(k/4)..+3 (word k%4).
  * IMPLICIT: call (j/4, ST_AUCTION) holds one word per auction j (word j%4); that word decides the click (word < T) and,
  * rescaled inside its sub-interval, is the competitor-bid uniform (orc_auction_outcome); the word 2^32-1 never wins;
@@ -406,6 +406,30 @@ ORC_API float orc_explicit_cost_from_word(uint32_t w, float bid)
     return fminf(fmaxf(v, 0.0f), 4.4f);
 }
 
+/* IMPLICIT_GENERAL, stream revision 3: the top k = min(B, top) of B iid Laplace(loc, |scale|) bids (rng.laplace,
+ * adcraft/synthetic_kw_classes.py:681-686), descending, as order statistics: t_1 = E_1 / B, t_2 = t_1 + E_2 / (B - 1), ... with
+ * E_i = -log(u_i) are -log of the top uniform order statistics (Renyi); the Laplace quantile at p = exp(-t) is
+ * loc + s (ln 2 - t) for p <= 1/2 and loc - s log(2 (1 - p)) above.  nth_price_auction only looks at the top (w + n). */
+ORC_API int32_t orc_top_laplace_bids(const uint32_t w[4], int32_t B, int32_t top, float loc, float scale, float out[4])
+{
+    const int32_t k = B < top ? B : top;
+    const float s = fabsf(scale);
+    float t = 0.0f;
+    for (int32_t i = 0; i < k && i < 4; ++i) {
+        const float e = -orc_det_logf(u23(w[i]));
+        t = t + e / (float)(B - i);
+        float z;
+        if (t >= 0.693147182464599609375f) z = 0.693147182464599609375f - t;
+        else {
+            float q = 1.0f - orc_det_expf(-t);
+            q = q > 5.9604644775390625e-08f ? q : 5.9604644775390625e-08f;
+            z = -orc_det_logf(q + q);
+        }
+        out[i] = fmaf(s, z, loc);
+    }
+    return k;
+}
+
 /* ------------------------------------------------------------------ nth_price_auction */
 /* synthetic_kw_helpers.py:116-180.  other_bids is [n_auctions][n_bidders] row-major.
  * Returns impressions; fills placements/costs (length = impressions). */
@@ -668,15 +692,16 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                     const uint32_t j = (uint32_t)(j0 + i);
                     int32_t m = 0;
                     for (int32_t z = 0; z < top - B; ++z) row[m++] = 0.0;            /* :156-161 zero bids */
-                    for (int32_t b = 0; b < B; ++b) {
-                        if (use_tape) row[m++] = tape->x_cost[bids_base + (int64_t)b * n + i];      /* (bidders, auctions) as drawn */
-                        else {
-                            uint32_t w[4];
-                            draw(key, j, (uint32_t)ST_GBID | ((uint32_t)(b >> 2) << 8), (uint32_t)k, tick, w);
-                            const uint32_t v = w[b & 3] >> 8;
-                            const float zf = v < 0x00800000u ? -orc_neg_log_u24(2u * v + 1u) : orc_neg_log_u24(2u * (0x00FFFFFFu - v) + 1u);
-                            row[m++] = (double)fmaf(fabsf(scale), zf, loc);          /* rng.laplace(bid_loc, bid_scale), :681-686 */
-                        }
+                    if (use_tape) {
+                        for (int32_t b = 0; b < B; ++b) row[m++] = tape->x_cost[bids_base + (int64_t)b * n + i];      /* (bidders, auctions) as drawn */
+                    } else if (B > 0) {
+                        /* the engine's stream (revision 3 for this model): only the top (w+n) bids of the B bidders matter below,
+                         * and they are drawn directly as order statistics from one call (orc_top_laplace_bids) */
+                        uint32_t w[4];
+                        float xs[4];
+                        draw(key, j, ST_GBID, (uint32_t)k, tick, w);
+                        const int32_t nb = orc_top_laplace_bids(w, B, top, loc, scale, xs);
+                        for (int32_t h = 0; h < nb; ++h) row[m++] = (double)xs[h];
                     }
                     qsort(row, (size_t)m, sizeof(double), cmp_f64);
                     const double *top_n = row + (m - top);                            /* the top (w+n), ascending (:152-155) */

@@ -243,3 +243,34 @@ def test_cents_to_dollars_is_the_ieee_quotient():
     assert L.orc_check_div100(0, 1 << 26) == 0
     assert L.orc_check_div100((1 << 31) - (1 << 22), 1 << 31) == 0
     assert L.orc_check_div100f(0, 1 << 24) == 0            # cents_to_dollars_f32: every |cents| below 2^24, both signs
+
+
+def test_top_laplace_bids_have_the_joint_law_of_the_sorted_draws():
+    """IMPLICIT_GENERAL, stream revision 3 (orc_top_laplace_bids / adc_law.h top_laplace_bids): the top (w + n) bids of an auction
+    drawn directly as order statistics must be distributed as the top of B sorted rng.laplace(loc, scale) draws
+    (adcraft/synthetic_kw_classes.py:681-686, synthetic_kw_helpers.py:152-155) - each order statistic (two-sample KS), the
+    descending order, and the dependence between neighbours (correlation of ranks), for small and large bidder pools"""
+    import ctypes as C
+    from scipy import stats
+    L.orc_top_laplace_bids.restype = C.c_int32
+    L.orc_top_laplace_bids.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(11)
+    n = 40000
+    loc, scale = 0.12, 0.07
+    for B, top in ((1, 3), (2, 3), (3, 3), (5, 4), (18, 3), (30, 4), (70, 3)):
+        words = rng.integers(0, 2**32, (n, 4), dtype=np.uint64).astype(np.uint32)
+        got = np.zeros((n, 4), np.float32)
+        k = min(B, top)
+        for i in range(n):
+            assert L.orc_top_laplace_bids(words[i].ctypes.data, B, top, loc, scale, got[i].ctypes.data) == k
+        got = got[:, :k].astype(np.float64)
+        assert (np.diff(got, axis=1) <= 0).all()                           # descending
+        ref = np.sort(rng.laplace(loc, scale, (n, B)), axis=1)[:, ::-1][:, :k]
+        for j in range(k):
+            assert stats.ks_2samp(got[:, j], ref[:, j]).pvalue > 1e-4, (B, top, j)
+        for j in range(k - 1):                                             # neighbours are dependent in the same way
+            r_got = stats.spearmanr(got[:, j], got[:, j + 1])[0]
+            r_ref = stats.spearmanr(ref[:, j], ref[:, j + 1])[0]
+            assert abs(r_got - r_ref) < 0.02, (B, top, j, r_got, r_ref)
+            gap_got, gap_ref = got[:, j] - got[:, j + 1], ref[:, j] - ref[:, j + 1]
+            assert stats.ks_2samp(gap_got, gap_ref).pvalue > 1e-4, (B, top, j, "gap")
