@@ -12,19 +12,29 @@
 //
 // One translation unit (so the device log table and all inlining stay local without -fgpu-rdc), in parts:
 //   parts/common.inc              device view of the engine (SoA pointers), wave scan/sum helpers, log table, drift
-//   parts/kernel_fast.inc         k_step_implicit_fast - the dominant kernel.  One workgroup per (env, 256-keyword
-//        tile): phase 1 one lane per keyword (coalesced SoA loads, pending drift, volume draw, state to LDS);
-//        phase 2 chunks of 16 auctions dealt round-robin to lanes, one Philox call per 4 auctions (stage A), paid
-//        clicks compacted through per-wave LDS rings for the conversion/revenue call (stage B), integer-cent
-//        totals by LDS atomics; phase 3 coalesced observation stores.  Ignores the budget; exact whenever the
-//        day's spend stays below it.
+//   parts/kernel_fast.inc         k_step_implicit_fast - the budget-free pass for dense keyword sets.  One workgroup per (env,
+//        256-keyword tile): phase 1 one lane per keyword (coalesced SoA loads, pending drift, volume draw, the keyword's two
+//        exact win intervals in word space and its law records in LDS); phase 2 work items of 16 / 8 / 4 whole Philox calls
+//        dealt lane-major, one word per auction, an auction = two subtract-and-compare pairs (stage A), clicked wins
+//        compacted through per-wave LDS rings for the price + conversion / revenue call on full wavefronts (stage B),
+//        integer-cent totals by LDS atomics; phase 3 coalesced observation stores.  Ignores the budget; exact whenever
+//        the day's spend stays below it.
+//   parts/kernel_sparse.inc       k_step_implicit_sparse - the same pass for keyword sets with few auctions per keyword (the
+//        host's volume hint): auctions classified against conservative win BRACKETS (float estimates with a guaranteed
+//        slack; the ~2e-5 of words in between take the long way), work items located through a byte list in LDS,
+//        parameters / env header / metric sums software-pipelined across the tiles of a workgroup.
 //   parts/kernel_exact_rows.inc   k_step_exact_rows - one workgroup per env: envs whose fast-pass spend reached the
 //        budget are re-run in the reference's order, a sub-timestep row of K cells at a time (parallel cell
 //        statistics, budget walk by prefix scans, ring-compacted conversions); then the step tail.
 //   parts/kernel_exact_serial.inc step_tail + k_step_exact - one wavefront per env walking cells serially: TAPE
-//        replay of the reference's recorded variates, the EXPLICIT model, and IMPLICIT with K > 1024.
+//        replay of the reference's recorded variates, the EXPLICIT / IMPLICIT_GENERAL hand-overs, IMPLICIT with K > 2048, and the
+//        read-only replay that regenerates a step's per-click lists (adc_engine_outcomes_replay).
+//   parts/kernel_explicit_fast.inc the other two keyword models, keyword-parallel: k_step_explicit_fast, k_step_general_fast (the
+//        reference's default ImplicitKeyword: top bids drawn as order statistics), k_step_float_day, k_step_explicit_rows.
 //   parts/kernels_misc.inc        drift, metric sums, ideal profit, keyword generation, reset, synthetic actions,
 //        flat observations/actions, nth_price_auction.
+//   parts/kernels_policy.inc      the callers of the step on the device: the zero-margin agent, the per-step ideal profit on
+//        the curves' contender lists (k_curve_contenders, k_ideal_from_contenders), the oracle bidder, per-env AKNCP / NCP.
 //   parts/host_api.inc            the engine object and the extern "C" entry points.
 //
 // No CPU path exists in this library.
