@@ -125,6 +125,7 @@ def lib():
         "adc_engine_profile_sample_every": ([vp, C.c_int32], C.c_int),
         "adc_engine_profile_read": ([vp, vp, C.POINTER(i64)], C.c_int),
         "adc_engine_profile_records": ([vp, C.POINTER(i64)], C.c_int),
+        "adc_engine_step_kernel_name": ([vp], C.c_char_p),
         "adc_engine_metrics_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_metrics_reset": ([vp], C.c_int),
         "adc_engine_metrics_read": ([vp, vp, vp], C.c_int),
@@ -132,7 +133,7 @@ def lib():
         "adc_bid_curves_from_samples": ([C.c_int, vp, i32, vp, i32, vp, vp], C.c_int),
         "adc_engine_metrics_akncp_ncp": ([vp, f64, vp, vp], C.c_int),
         "adc_engine_bid_curves_contenders": ([vp, vp, vp, C.POINTER(i32)], C.c_int),
-        "adc_engine_outcomes_replay": ([vp, i32, vp, f32, i64, vp, vp, vp, vp, C.POINTER(i64), vp], C.c_int),
+        "adc_engine_outcomes_replay": ([vp, i32, i32, vp, f32, i64, vp, vp, vp, vp, C.POINTER(i64), vp], C.c_int),
         "adc_nth_price_auction": ([C.c_int, f64, vp, i32, i32, i32, i32, C.POINTER(i32), vp, vp], C.c_int),
         "adc_sigmoid": ([f64, f64, f64], f64),
         "adc_clamp": ([f64, f64, f64], f64),

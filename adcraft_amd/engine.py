@@ -229,9 +229,10 @@ class StepEngine:
         _check_overflow(self._overflow)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
-    def outcomes_replay(self, env, bids_k, budget):
-        """the paid clicks of env `env`'s LAST step, one by one, in the reference's order (adc_engine_outcomes_replay): dict of
-        keyword, timestep, cost (dollars), revenue (dollars, -1 = no conversion) and share_volume [K].  Call before the next step."""
+    def outcomes_replay(self, env, bids_k, budget, steps_back=1):
+        """the paid clicks of one step of env `env` (steps_back = 1: its last), one by one, in the reference's order
+        (adc_engine_outcomes_replay): dict of keyword, timestep, cost (dollars), revenue (dollars, -1 = no conversion) and
+        share_volume [K].  An earlier step can be replayed while drift is off and nothing has changed the parameters since."""
         K = self.num_keywords
         bids = np.ascontiguousarray(bids_k, dtype=np.float32).reshape(K)
         share = np.zeros(K, np.int32)
@@ -240,7 +241,7 @@ class StepEngine:
         while True:
             kw, ts = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
             cost, rev = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
-            check(self._lib.adc_engine_outcomes_replay(self._h, int(env), bids.ctypes.data, float(budget), cap, kw.ctypes.data, ts.ctypes.data,
+            check(self._lib.adc_engine_outcomes_replay(self._h, int(env), int(steps_back), bids.ctypes.data, float(budget), cap, kw.ctypes.data, ts.ctypes.data,
                                                        cost.ctypes.data, rev.ctypes.data, C.byref(n), share.ctypes.data))
             if n.value <= cap:
                 m = n.value
@@ -330,6 +331,10 @@ class StepEngine:
         n = C.c_int64()
         check(self._lib.adc_engine_profile_records(self._h, C.byref(n)))
         return n.value
+
+    def step_kernel_name(self):
+        """the first-pass kernel of the last step (the one profile_read()'s first duration times)"""
+        return self._lib.adc_engine_step_kernel_name(self._h).decode()
 
     def metrics_enable(self, on=True):
         check(self._lib.adc_engine_metrics_enable(self._h, 1 if on else 0))

@@ -14,12 +14,12 @@ What differs from the reference, on purpose (DESIGN.md "quirks"):
   * bids are canonicalised to integer cents (numpy-1.x promotion semantics, SURVEY B-9);
   * info["bidding_outcomes"] is formatted only when somebody reads it: the per-click lists of src/lib.rs:251-275 never
     exist in a fused kernel, but every variate is addressed by what it is for, so they are regenerated exactly by a
-    read-only second walk of the step (adc_engine_outcomes_replay) - at the latest when the next step begins, and only
-    if the info dict is still alive then;
+    read-only second walk of that step (adc_engine_outcomes_replay).  step() itself does nothing for it.  An info dict
+    read late (after a reset, a parameter change, or - with drift on - after the next step) carries the step's
+    per-keyword totals instead and says 'per_click': 'expired';
   * only updater_mask None or all-True is supported (the only masks the reference's configs use; a
     partial mask mis-aligns coefficients in the reference, gymnasium_kw_env.py:136-144).
 """
-import weakref
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -67,10 +67,6 @@ class _Lazy:
             self._s = self._fn()
             self._fn = None
         return self._s
-
-    def settle(self):
-        """format now (the engine is about to move on)"""
-        str(self)
 
     __repr__ = __str__
 
@@ -147,6 +143,8 @@ class BiddingSimulation(_EnvBase):
         self._engine = None
         self._params_host = None          # the reference-format keyword_params list (mutable lists)
         self._params_dirty = False
+        self._serial = 0                  # steps taken since the stream was last (re)keyed or the parameters last changed
+        self._epoch = 0                   # bumped by whatever ends the replayability of earlier steps
         self.current_day = 0
         self.cumulative_profit = 0.0
         if updater_mask is not None:
@@ -175,11 +173,11 @@ class BiddingSimulation(_EnvBase):
         """gymnasium_kw_env.py:114-158, on the device (engine drift stream)"""
         if self.updater_mask is None:
             return
-        self._settle_outcomes()
         assert len(self.updater_mask) == self.num_keywords
         assert self._engine is not None, "reset required, need to generate keywords to bid on"
         self._engine.update_keywords()
         self._params_dirty = True
+        self._epoch += 1
 
     # ------------------------------------------------------------------ keyword state
     @property
@@ -206,6 +204,7 @@ class BiddingSimulation(_EnvBase):
             planes = utils.explicit_params_to_planes([tuple(p) for p in self._params_host])
         self._engine.set_env_params(0, planes)
         self._params_dirty = False
+        self._epoch += 1
 
     def _ensure_engine(self, seed):
         if self._engine is None:
@@ -217,8 +216,8 @@ class BiddingSimulation(_EnvBase):
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
-        self._settle_outcomes()
         super().reset(seed=seed)
+        self._epoch += 1
         resample = seed is not None or not self._have_keywords          # gymnasium_kw_env.py:303
         self._ensure_engine(seed)
         if resample:
@@ -261,7 +260,6 @@ class BiddingSimulation(_EnvBase):
         bids64 = np.asarray(bid_array, dtype=np.float64).reshape(self.num_keywords)
         rounded = np.round(np.maximum(bids64, 0.01), 2)                                      # :215 (f64: B-9)
         bids = rounded.tolist()
-        self._settle_outcomes()
         out = self._engine.step(rounded.astype(np.float32)[None, :],
                                 np.float32(np.asarray(self.budget, dtype=np.float64).reshape(-1)[0]), copy=False)
         profits = float(out["reward"][0])
@@ -282,8 +280,9 @@ class BiddingSimulation(_EnvBase):
             self._params_dirty = True            # update_keywords() ran on the device (:246)
         snap = dict(observations)            # (the arrays are this step's own copies; formatted only if somebody looks)
         budget_used = float(np.float32(np.asarray(self.budget, dtype=np.float64).reshape(-1)[0]))
-        outcomes = _Lazy(lambda: self._repr_outcomes(bids, snap, self._engine.outcomes_replay(0, rounded.astype(np.float32), budget_used)))
-        self._pending_outcomes = weakref.ref(outcomes)        # settled when the next step begins, if anybody still holds the info
+        self._serial += 1
+        serial, epoch = self._serial, self._epoch
+        outcomes = _Lazy(lambda: self._outcomes_text(serial, epoch, bids, rounded.astype(np.float32), budget_used, snap))
         info = {
             "bids": bids,
             "bidding_outcomes": outcomes,
@@ -302,14 +301,18 @@ class BiddingSimulation(_EnvBase):
                                    + f"but our cumulative loss was ({self.cumulative_profit:.2f})")
         return observations, reward, terminated, truncated, info
 
-    def _settle_outcomes(self):
-        """the previous step's info["bidding_outcomes"] can only be regenerated while the engine still stands where that step
-        left it: if the caller kept the info dict, format it now"""
-        ref = getattr(self, "_pending_outcomes", None)
-        self._pending_outcomes = None
-        lazy = ref() if ref is not None else None
-        if lazy is not None:
-            lazy.settle()
+    def _outcomes_text(self, serial, epoch, bids, bids_f32, budget_used, obs):
+        """info["bidding_outcomes"] of the step with this serial, formatted when somebody reads it.  The per-click lists are
+        regenerated by replaying that step's stream position read-only (StepEngine.outcomes_replay); nothing is done at step
+        time, so a loop that never looks pays nothing.  The last step can always be replayed; an earlier one while its episode
+        is still running, drift is off and the keyword parameters have not been touched since.  Past that the clicks cannot be
+        regenerated: the text then carries the step's per-keyword totals (exact) with one-element lists, and says so under
+        'per_click'."""
+        back = self._serial - serial + 1
+        replayable = (self._engine is not None and epoch == self._epoch and (back == 1 or not self._drift_on()))
+        if replayable:
+            return self._repr_outcomes(bids, obs, self._engine.outcomes_replay(0, bids_f32, budget_used, steps_back=back))
+        return self._repr_outcomes(bids, obs, None)
 
     @staticmethod
     def _repr_outcomes(bids, obs, clicks):
@@ -322,6 +325,14 @@ class BiddingSimulation(_EnvBase):
 
         K = len(bids)
         rows = []
+        if clicks is None:                                  # expired (see _outcomes_text): the step's totals only
+            for k, b in enumerate(bids):
+                c, r = float(obs["cost"][k]), float(obs["revenue"][k])
+                rows.append("{" + f"'bid': {disp(b)}, 'impressions': {int(obs['impressions'][k])}, "
+                            f"'buyside_clicks': {int(obs['buyside_clicks'][k])}, 'costs': [{c!r}], "
+                            f"'sellside_conversions': {int(obs['sellside_conversions'][k])}, 'revenues': [{r!r}], "
+                            f"'profit': {disp(r - c)}, 'per_click': 'expired'" + "}")
+            return "[" + ", ".join(rows) + "]"
         by_kw = [[] for _ in range(K)]
         for i in range(len(clicks["keyword"])):
             by_kw[int(clicks["keyword"][i])].append(i)
@@ -356,7 +367,7 @@ class BiddingSimulation(_EnvBase):
             return self._current_text
 
     def close(self):
-        self._settle_outcomes()
+        self._epoch += 1
         if self._engine is not None:
             self._engine.close()
             self._engine = None

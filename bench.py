@@ -140,6 +140,7 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
     units = float(world) * N * K * steps
     b_alg = BYTES_PER_U[drift] * N * K + BYTES_PER_ENV * N            # algorithmic bytes per launch (one GPU)
     dom = int(np.argmax(kernel_ms))              # the dominant kernel of the step
+    step_kernel = eng.step_kernel_name()         # (which of the keyword-parallel kernels the engine chose for this workload)
     k_ms = kernel_ms[dom] / max(launches, 1)
     achieved = b_alg / (k_ms * 1e-3) / 1e9 if launches else None
     notes = pmc_notes(cfg_name) if dom == 0 else {}
@@ -154,12 +155,12 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": notes.get("hbm_bytes_per_launch"),
                      "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else None),
-                     "kernel": KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps,
+                     "kernel": step_kernel if dom == 0 else KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps,
                      "event_records_in_timed_region": int(records_in_timed_region),
                      "kernel_ms_method": f"HIP events on the engine's stream around every step of a separate, untimed pass of {steps} steps "
                                          "run between the warm-up and the timed region (same process, same state; the timed region itself "
                                          "records no event); rocprofv3 --kernel-trace --stats of the same command: profiles/",
-                     "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip(KERNEL_NAMES, kernel_ms)},
+                     "all_kernels_ms": {n: m / max(launches, 1) for n, m in zip((step_kernel,) + KERNEL_NAMES[1:], kernel_ms)},
                      "algorithmic_bytes_per_launch": b_alg},
     }
     valu = notes.get("valu")
@@ -169,7 +170,7 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         # full-rate opcodes (profiles/r02_issue_rates.md: compares, converts, min/max, integer multiplies cost 4 cycles)
         lane_ops = valu["wave_instructions_per_launch"] * 64.0 / (k_ms * 1e-3)
         res["roofline_valu"] = {"bound": "valu", "achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-instructions/s",
-                                "frac": lane_ops / VALU_PEAK_LANE_OPS, "kernel": KERNEL_NAMES[0], "kernel_ms": k_ms,
+                                "frac": lane_ops / VALU_PEAK_LANE_OPS, "kernel": step_kernel, "kernel_ms": k_ms,
                                 "valu_wave_instructions_per_launch": valu["wave_instructions_per_launch"],
                                 "valu_lane_instructions_per_auction": valu.get("valu_lane_instructions_per_auction"),
                                 "source": "instruction count: " + str(notes.get("source_note")) + "; kernel time: HIP events in this run"}

@@ -264,6 +264,10 @@ int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, int64_t *lau
 /* hipEventRecord calls the engine has issued since it was created (four per bracketed step): lets a benchmark show that
  * its timed region recorded none */
 int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
+/* name of the kernel the last step's first pass ran (the one kernel_ms_total[0] times): "k_step_implicit_fast<false>",
+ * "k_step_implicit_fast<true>" (narrow tiles), "k_step_implicit_sparse", "k_step_general_fast", "k_step_explicit_fast", or
+ * "k_step_exact" after a tape replay; "" before the first step.  A static string: do not free. */
+const char *adc_engine_step_kernel_name(adc_engine *e);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------------------------- */
 /* Envs shard over the GPUs of a node, one process (one engine) per GPU; nothing on the step path communicates.  The
@@ -365,15 +369,17 @@ int adc_engine_metrics_akncp_ncp(adc_engine *e, double days, double *akncp_n, do
 /* ---- info["bidding_outcomes"] on demand (src/lib.rs:251-275, adcraft/gymnasium_kw_env.py:247-251) -------------------- */
 /* The fused step kernels keep per-keyword totals, not the per-click lists the reference formats ('costs', 'revenues',
  * 'revenues_per_cost').  Every variate is addressed by (env key; index, stage, keyword, tick), so those lists can be
- * regenerated exactly, only when somebody reads them: this call walks env `env`'s LAST step once more, read-only, in the
- * reference's order (sub-timestep, keyword, auction; the budget walk in its floating point) and lists the paid clicks:
- * keyword[i], timestep[i], cost[i] (dollars), revenue[i] (dollars; -1 = the click did not convert).  *count = paid clicks
- * of the step (may exceed capacity: then only `capacity` are stored).  share_volume_k[K] (optional) = per keyword, the
- * auctions of the sub-timesteps that had an impression - the denominator combine_outcomes ends up with for
- * 'impression_share' (bidding_simulation.py:130-146).  Call it before the next step of the engine; `bids_k` and `budget`
- * are the step's action for this env.  ADC_ESTATE after a tape replay or before any step. */
-int adc_engine_outcomes_replay(adc_engine *e, int32_t env, const float *bids_k, float budget, int64_t capacity, int32_t *keyword,
-                               int32_t *timestep, double *cost, double *revenue, int64_t *count, int32_t *share_volume_k);
+ * regenerated exactly, only when somebody reads them: this call walks one env-step once more, read-only, in the reference's
+ * order (sub-timestep, keyword, auction; the budget walk in its floating point) and lists the paid clicks: keyword[i],
+ * timestep[i], cost[i] (dollars), revenue[i] (dollars; -1 = the click did not convert).  steps_back = 1: env `env`'s LAST
+ * step; k > 1: the k-th last - valid while no reset / tape replay lies in between, drift is off and the caller has not
+ * changed the env's parameters since (the stream position is recomputed, the parameters are read as they stand).  *count =
+ * paid clicks of the step (may exceed capacity: then only `capacity` are stored).  share_volume_k[K] (optional) = per
+ * keyword, the auctions of the sub-timesteps that had an impression - the denominator combine_outcomes ends up with for
+ * 'impression_share' (bidding_simulation.py:130-146).  `bids_k` and `budget` are that step's action for this env.
+ * ADC_ESTATE when the step cannot be replayed. */
+int adc_engine_outcomes_replay(adc_engine *e, int32_t env, int32_t steps_back, const float *bids_k, float budget, int64_t capacity,
+                               int32_t *keyword, int32_t *timestep, double *cost, double *revenue, int64_t *count, int32_t *share_volume_k);
 
 /* ---- standalone auction clearing (adcraft/synthetic_kw_helpers.py:116-180) ------------------------ */
 /* other_bids: host double [n_auctions][n_bidders]; placements/costs: host, capacity n_auctions.

@@ -91,10 +91,38 @@ def test_bidding_outcomes_lists_every_click_on_demand(pkg, implicit, budget):
         assert spend <= budget + 1e-9
         bound = bound or spend > budget - 2.0
     assert bound == (budget < 1e5)                           # the small budgets really bound
-    for (late_info, text_then) in kept:                      # settled when the twin's next step began (the dict was alive)
+    for (late_info, text_then) in kept:                      # an earlier step of the running episode replays just the same
         assert str(late_info["bidding_outcomes"]) == text_then
     env.close()
     twin.close()
+
+
+def test_bidding_outcomes_cost_nothing_unread_and_expire_honestly(pkg):
+    """step() does nothing for info["bidding_outcomes"]: a loop that keeps the previous info alive (the usual `obs, r, term,
+    trunc, info = env.step(a)`) does not trigger a replay.  With drift on only the last step can be regenerated; after a reset
+    none of the earlier ones: the late string carries the step's totals and says so."""
+    import ast
+    env = pkg.BiddingSimulation(keyword_config=_cfg(40, 0.5), num_keywords=16, updater_mask=[True] * 16)
+    env.reset(seed=3)
+    calls = []
+    real = env._engine.outcomes_replay
+    env._engine.outcomes_replay = lambda *a, **k: (calls.append(k.get("steps_back", 1)), real(*a, **k))[1]
+    act = {"keyword_bids": np.full(16, 0.9), "budget": np.array([1.0e6])}
+    infos = []
+    for _ in range(3):
+        obs, r, term, trunc, info = env.step(act)
+        infos.append((info, obs))
+    assert calls == []
+    last = ast.literal_eval(str(infos[2][0]["bidding_outcomes"]))
+    assert calls == [1] and "per_click" not in last[0] and len(last[0]["costs"]) == infos[2][1]["buyside_clicks"][0]
+    old = ast.literal_eval(str(infos[0][0]["bidding_outcomes"]))              # drift has moved the parameters since
+    assert calls == [1] and old[0]["per_click"] == "expired"
+    assert [round(r["costs"][0] * 100) for r in old] == [round(float(c) * 100) for c in infos[0][1]["cost"]]
+    assert [r["buyside_clicks"] for r in old] == list(infos[0][1]["buyside_clicks"])
+    env.reset()
+    late = ast.literal_eval(str(infos[1][0]["bidding_outcomes"]))
+    assert late[0]["per_click"] == "expired" and calls == [1]
+    env.close()
 
 
 def test_reset_seed_reproduces_reference_keywords(pkg, golden):

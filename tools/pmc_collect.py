@@ -46,7 +46,7 @@ rec = {
              "lds_active_quad_cycles": m["SQ_ACTIVE_INST_LDS"], "grbm_gui_active": m["GRBM_GUI_ACTIVE"], "waves": m["SQ_WAVES"],
              "auctions_per_launch_expected": auctions,
              "valu_lane_instructions_per_auction": m["SQ_INSTS_VALU"] * 64.0 / auctions},
-    "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 2); "
+    "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 3); "
                    "FETCH_SIZE doubled per the gfx950 correction; bench runs in metric mode (+16 B per keyword-step of accumulator traffic)",
 }
 with open(os.path.join(out, f"pmc_{cfg}.json"), "w") as f:
