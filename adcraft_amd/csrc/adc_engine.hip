@@ -26,6 +26,10 @@
 //   parts/kernel_exact_rows.inc   k_step_exact_rows - one workgroup per env: envs whose fast-pass spend reached the
 //        budget are re-run in the reference's order, a sub-timestep row of K cells at a time (parallel cell
 //        statistics, budget walk by prefix scans, ring-compacted conversions); then the step tail.
+//   parts/kernel_click_walk.inc   k_step_click_walk - binding budgets, K <= 256: the fast pass lists its clicked wins for envs whose
+//        budget bound the day before; this kernel sorts the list into the reference's order (counting sort over the 24 x K
+//        cells in LDS) and walks it - paid in full while the running total fits, click by click in the reference's float
+//        arithmetic after - instead of re-running the day row by row.  Hands anything unusual to k_step_exact_rows.
 //   parts/kernel_exact_serial.inc step_tail + k_step_exact - one wavefront per env walking cells serially: TAPE
 //        replay of the reference's recorded variates, the EXPLICIT / IMPLICIT_GENERAL hand-overs, IMPLICIT with K > 2048, and the
 //        read-only replay that regenerates a step's per-click lists (adc_engine_outcomes_replay).
@@ -60,6 +64,7 @@ namespace adck {
 #include "parts/kernel_fast.inc"
 #include "parts/kernel_sparse.inc"
 #include "parts/kernel_exact_rows.inc"
+#include "parts/kernel_click_walk.inc"
 #include "parts/kernel_exact_serial.inc"
 #include "parts/kernel_explicit_fast.inc"
 #include "parts/kernels_misc.inc"

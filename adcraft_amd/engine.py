@@ -332,6 +332,12 @@ class StepEngine:
         check(self._lib.adc_engine_profile_records(self._h, C.byref(n)))
         return n.value
 
+    def walk_stats(self, reset=False):
+        """k_step_click_walk's counters on this device: [walked, list overflowed, campaign stopped, other hand-overs] (adc_debug_walk_stats)"""
+        out = np.zeros(4, dtype=np.int64)
+        check(self._lib.adc_debug_walk_stats(self._h, out.ctypes.data, 1 if reset else 0))
+        return out
+
     def step_kernel_name(self):
         """the first-pass kernel of the last step (the one profile_read()'s first duration times)"""
         return self._lib.adc_engine_step_kernel_name(self._h).decode()

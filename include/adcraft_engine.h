@@ -415,6 +415,10 @@ int64_t adc_check_win_brackets(int64_t n, const float *bid, const float *cost_lo
 /* diagnostic: the stream's generator (Philox4x32, the stream's round count) evaluated on the device for n counters ctr4[n][4]
  * and keys key2[n][2] -> out4[n][4]; tests compare it with the CPU battery's generator (oracle/stream_battery.c) */
 int adc_debug_philox_device(int device_id, int64_t n, const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);
+/* counters of k_step_click_walk on the engine's device since the library was loaded (or the last call with reset != 0):
+ * stats[0] env-steps walked, [1] handed to the row kernel because the click list overflowed, [2] because the campaign
+ * stopped, [3] for another reason (budget <= 0, a keyword-day above 2^22 cents in metric mode).  Test / measurement aid. */
+int adc_debug_walk_stats(adc_engine *e, int64_t stats[4], int reset);
 int adc_debug_win_brackets_device(int device_id, int64_t n, const float *bid, const float *cost_loc, const float *cost_scale,
                                   const float *buyside_ctr, uint32_t *out8);
 

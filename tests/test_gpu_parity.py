@@ -178,6 +178,60 @@ def test_binding_budget_matches_oracle(amd, budget):
     assert n > 0          # the exact pass really ran
 
 
+@pytest.mark.parametrize("case", ["dense_256", "narrow_tiles", "budget_ground_down", "tiny_budget", "alternating", "drift_metrics", "filtered_lists",
+                                  "filtered_tiny_budget", "too_many_clicks", "overflow", "off"])
+def test_click_walk_matches_oracle(amd, monkeypatch, case):
+    """k_step_click_walk (binding budgets, K <= 256): from the second binding day on the fast pass lists its clicked wins and
+    the walk over the sorted lists replaces the row-by-row re-run.  Bit-exact against the oracle (which knows neither), with the
+    counters showing that the path really ran - complete lists, lists filtered by the previous day's hints (a day of more clicks
+    than one group holds), campaigns that stop (tiny budgets: the impressions after the stop are taken off again); a list that
+    overflows, a day with more clicks than the lists are worth, and the path switched off give the same results through the row
+    kernel."""
+    N, K, vol, steps, budgets = 6, 256, 40, 5, [400.0]
+    drift = metrics = False
+    if case == "narrow_tiles": N, K, budgets = 2, 100, [90.0]
+    if case == "budget_ground_down": budgets = [60.0]
+    if case == "tiny_budget": budgets = [0.37]
+    if case == "alternating": budgets, steps = [300.0, 300.0, 1e9, 300.0, 1e9, 1e9, 200.0, 200.0], 8
+    if case == "drift_metrics": drift = metrics = True; N, K = 5, 200
+    if case in ("filtered_lists", "filtered_tiny_budget"):
+        vol, steps, budgets = 110, 6, [900.0] if case == "filtered_lists" else [0.9]
+        monkeypatch.setenv("ADCRAFT_CLICK_WALK_MAX", "100000")
+    if case == "too_many_clicks": vol = 110
+    if case == "overflow": monkeypatch.setenv("ADCRAFT_CLICK_CAP", "16")
+    if case == "off": monkeypatch.setenv("ADCRAFT_CLICK_WALK", "0")
+    planes = H.implicit_params(N, K, seed=41, mean_volume=vol)
+    e = amd.StepEngine(N, K, seed=9, drift_enabled=drift)
+    e.set_all_params(planes)
+    e.reset()
+    e.walk_stats(reset=True)
+    if metrics:
+        e.metrics_enable(True)
+        e.metrics_reset()
+    o = H.mirror_oracle(e, planes, drift_on=drift)
+    prof = np.zeros(K, dtype=np.int64)
+    bound = 0
+    for s in range(steps):
+        budget = budgets[s % len(budgets)]
+        bids = o.sample_bids(0.4, 1.2)
+        got, ref = e.step(bids, budget), o.step(bids, budget)
+        H.assert_step_equal(got, ref, implicit=True)
+        bound += int((ref["cost_cents"].sum(axis=1) >= np.rint(np.float64(np.float32(budget)) * 100)).sum())
+        prof += (np.rint(got["revenue"].astype(np.float64) * 100) - np.rint(got["cost"].astype(np.float64) * 100)).sum(axis=0).astype(np.int64)
+    walked, overflowed, stopped, other = e.walk_stats()
+    assert bound > 0
+    if case in ("off", "too_many_clicks"): assert walked + overflowed + stopped + other == 0
+    elif case == "overflow": assert overflowed > 0 and walked == 0
+    else: assert walked > 0 and overflowed == 0 and walked + other >= bound - 2 * N       # all but each env's first binding day(s)
+    if case in ("tiny_budget", "filtered_tiny_budget"): assert stopped > 0
+    if metrics:
+        kp, sc = e.metrics_read()
+        assert np.array_equal(kp, prof)
+        o.materialize_drift()
+        assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+
+
 def test_mixed_binding_and_not(amd):
     """some envs hit the budget, others do not, in the same launch"""
     N, K = 8, 64

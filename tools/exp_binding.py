@@ -28,7 +28,9 @@ for budget in (1e9, 1000.0, 10.0, 1.0):
     eng.set_all_params(planes)
     eng.reset()
     eng.sample_actions(0.30, 1.00, budget)
-    print(f"cfg2 IMPLICIT 4096 x 256, budget {budget:g}: {device_ms(eng):.3f} ms/step", flush=True)
+    eng.walk_stats(reset=True)
+    print(f"cfg2 IMPLICIT 4096 x 256, budget {budget:g}: {device_ms(eng):.3f} ms/step   click walk [walked, overflowed, stopped, other] = "
+          f"{eng.walk_stats().tolist()}", flush=True)
     eng.close()
 eng = StepEngine(1, 100, seed=3, max_days=1 << 30, loss_threshold=1e15)
 eng.set_all_params(planes[:, :1, :100])
@@ -42,7 +44,8 @@ for budget in (1e9, 30.0):
     t0 = time.perf_counter()
     for _ in range(200):
         eng.step(bids, bud, copy=False)
-    print(f"1 env x 100 keywords, budget {budget:g}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us/step (host in / host out)", flush=True)
+    print(f"1 env x 100 keywords, budget {budget:g}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us/step (host in / host out)   click walk "
+          f"{eng.walk_stats(reset=True).tolist()}", flush=True)
 eng.close()
 from tests import helpers as H  # noqa: E402
 xp = H.explicit_params(N, K, seed=5)
