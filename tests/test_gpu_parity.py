@@ -264,6 +264,41 @@ def test_explicit_matches_oracle(amd, budget):
     _run_vs_oracle(amd, N, K, planes, steps=3, budget=budget, model=1, bid_lo=0.05, bid_hi=2.0)
 
 
+@pytest.mark.parametrize("model,K", [(1, 300), (1, 512), (1, 700), (1, 1024), (2, 300), (2, 1000)])
+def test_float_day_kernel_beyond_256_keywords(amd, model, K):
+    """binding budgets for the float-money models at 256 < K <= 1024: the day kernel with 512 / 1024 lanes (lane = keyword) instead
+    of the one-wavefront walkers - bit-exact against the oracle with drift, budgets that bind early, late and not at all, and the
+    hint that skips the keyword-parallel pass the day after a binding one"""
+    N = 3
+    if model == 1:
+        planes = H.explicit_params(N, K, seed=51)
+        extra = {}
+        lo, hi, budgets = 0.05, 2.0, (K * 1.5, K * 1.5, 1e9, K * 0.1, 1e9, K * 4.0)
+    else:
+        rng = np.random.default_rng(52)
+        planes = np.stack([rng.integers(0, 60, (N, K)), rng.random((N, K)) * 6, rng.uniform(0.0, 0.3, (N, K)), rng.uniform(0.05, 0.15, (N, K)),
+                           rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.3, 1.5, (N, K)),
+                           rng.uniform(0.02, 0.3, (N, K))]).astype(np.float32)
+        extra = dict(max_bidders=30, participation_rate=0.6, num_winners=1)
+        lo, hi, budgets = 0.05, 0.5, (K * 0.05, K * 0.05, 1e9, K * 0.004, 1e9, K * 0.2)
+    e = amd.StepEngine(N, K, model=model, seed=17, drift_enabled=True)
+    if model == 2:
+        e.set_general_model(30, 0.6, 1)
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes, drift_on=True, **extra)
+    bound = 0
+    for b in budgets:
+        bids = o.sample_bids(lo, hi)
+        got, ref = e.step(bids, b), o.step(bids, b)
+        H.assert_step_equal(got, ref, implicit=False)
+        bound += int((ref["cost"].astype(np.float64).sum(axis=1) >= 0.98 * b).sum())
+    assert bound >= N          # the budgets really bound
+    o.materialize_drift()
+    assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+
+
 @pytest.mark.parametrize("case", ["full_width", "pool_exhausted", "huge_cells", "no_budget", "narrow", "drift_with_hint"])
 def test_explicit_day_kernel_and_its_fallbacks(amd, case):
     """k_step_explicit_day (K <= 256: lane = keyword, one row of click lists in LDS) against the oracle, and every way out
