@@ -179,7 +179,7 @@ def test_binding_budget_matches_oracle(amd, budget):
 
 
 @pytest.mark.parametrize("case", ["dense_256", "narrow_tiles", "budget_ground_down", "tiny_budget", "alternating", "drift_metrics", "filtered_lists",
-                                  "filtered_tiny_budget", "too_many_clicks", "overflow", "off"])
+                                  "filtered_tiny_budget", "too_many_clicks", "binds_at_once", "overflow", "off"])
 def test_click_walk_matches_oracle(amd, monkeypatch, case):
     """k_step_click_walk (binding budgets, K <= 256): from the second binding day on the fast pass lists its clicked wins and
     the walk over the sorted lists replaces the row-by-row re-run.  Bit-exact against the oracle (which knows neither), with the
@@ -187,17 +187,20 @@ def test_click_walk_matches_oracle(amd, monkeypatch, case):
     than one group holds), campaigns that stop (tiny budgets: the impressions after the stop are taken off again); a list that
     overflows, a day with more clicks than the lists are worth, and the path switched off give the same results through the row
     kernel."""
-    N, K, vol, steps, budgets = 6, 256, 40, 5, [400.0]
+    N, K, vol, steps, budgets = 6, 256, 40, 5, [900.0]       # (a day costs ~1300 here, 40 % of it in sub-timestep 0)
     drift = metrics = False
-    if case == "narrow_tiles": N, K, budgets = 2, 100, [90.0]
+    if case == "narrow_tiles": N, K, budgets = 2, 100, [330.0]
     if case == "budget_ground_down": budgets = [60.0]
     if case == "tiny_budget": budgets = [0.37]
-    if case == "alternating": budgets, steps = [300.0, 300.0, 1e9, 300.0, 1e9, 1e9, 200.0, 200.0], 8
+    if case == "alternating": budgets, steps = [850.0, 850.0, 1e9, 850.0, 1e9, 1e9, 700.0, 700.0], 8
     if case == "drift_metrics": drift = metrics = True; N, K = 5, 200
     if case in ("filtered_lists", "filtered_tiny_budget"):
-        vol, steps, budgets = 110, 6, [900.0] if case == "filtered_lists" else [0.9]
+        vol, steps, budgets = 110, 6, [2200.0] if case == "filtered_lists" else [0.9]
         monkeypatch.setenv("ADCRAFT_CLICK_WALK_MAX", "100000")
     if case == "too_many_clicks": vol = 110
+    if case == "binds_at_once":                              # in sub-timestep 0, and asked to keep such days off the lists
+        budgets = [200.0]
+        monkeypatch.setenv("ADCRAFT_CLICK_WALK_MIN_ROW", "2")
     if case == "overflow": monkeypatch.setenv("ADCRAFT_CLICK_CAP", "16")
     if case == "off": monkeypatch.setenv("ADCRAFT_CLICK_WALK", "0")
     planes = H.implicit_params(N, K, seed=41, mean_volume=vol)
@@ -220,7 +223,7 @@ def test_click_walk_matches_oracle(amd, monkeypatch, case):
         prof += (np.rint(got["revenue"].astype(np.float64) * 100) - np.rint(got["cost"].astype(np.float64) * 100)).sum(axis=0).astype(np.int64)
     walked, overflowed, stopped, other = e.walk_stats()
     assert bound > 0
-    if case in ("off", "too_many_clicks"): assert walked + overflowed + stopped + other == 0
+    if case in ("off", "too_many_clicks", "binds_at_once"): assert walked + overflowed + stopped + other == 0
     elif case == "overflow": assert overflowed > 0 and walked == 0
     else: assert walked > 0 and overflowed == 0 and walked + other >= bound - 2 * N       # all but each env's first binding day(s)
     if case in ("tiny_budget", "filtered_tiny_budget"): assert stopped > 0
