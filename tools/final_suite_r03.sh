@@ -18,6 +18,8 @@ echo "pmc done"
 for b in 1000 10 1; do timeout -k 10 200 python3 bench.py --config cfg2 --budget $b --no-cpu-baseline > $OUT/bench_budget$b.json 2>> $OUT/bench.err || exit 1; done
 timeout -k 10 200 python3 tools/exp_binding.py > $OUT/binding.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/exp_binding_wide.py > $OUT/binding_wide.txt 2>&1 || exit 1
+timeout -k 10 400 python3 tools/exp_binding_ctr.py > $OUT/binding_ctr.txt 2>&1 || exit 1
+timeout -k 10 400 python3 tools/exp_binding_wide_float.py > $OUT/binding_wide_float.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_general.py > $OUT/general_model.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_ideal_step.py > $OUT/ideal_step.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_closed_loop.py > $OUT/closed_loop.txt 2>&1 || exit 1
