@@ -26,6 +26,9 @@
 //   parts/kernel_exact_rows.inc   k_step_exact_rows - one workgroup per env: envs whose fast-pass spend reached the
 //        budget are re-run in the reference's order, a sub-timestep row of K cells at a time (parallel cell
 //        statistics, budget walk by prefix scans, ring-compacted conversions); then the step tail.
+//        Since round 3 it stops at the row after the one the budget bound in and parks the env for k_step_rest_of_day (same file):
+//        the remaining rows' auctions in whole Philox calls, wins counted by exact word intervals, the few cells that may hold
+//        an affordable click walked in order.
 //   parts/kernel_click_walk.inc   k_step_click_walk - binding budgets, K <= 256: the fast pass lists its clicked wins for envs whose
 //        budget bound the day before; this kernel sorts the list into the reference's order (counting sort over the 24 x K
 //        cells in LDS) and walks it - paid in full while the running total fits, click by click in the reference's float

@@ -32,13 +32,13 @@ while time.time() - t0 < budget_s:
     if rng.random() < 0.2:
         planes[3] *= np.float32(rng.choice([0.0, 5.0]))                                           # degenerate / wide competitor
     if explicit:
-        K = min(K, 300)
+        K = min(K, 1100)                          # (the 512- and 1024-lane day kernels, and the walkers beyond)
         planes = H.explicit_params(N, K, seed=int(rng.integers(1 << 30)))
         if rng.random() < 0.3:
             planes[0] *= np.float32(rng.choice([0.0, 4.0]))          # no volume / ~100 auctions
     pool = None
     if general:                                   # tens of competitor bids per auction: keep the oracle's share of the time small
-        K = min(K, 257)
+        K = min(K, 700)
         planes = H.implicit_params(N, K, seed=int(rng.integers(1 << 30)), mean_volume=float(rng.choice([0, 3, 20, 60])), cvr=float(rng.uniform(0, 1)),
                                    no_vol_prob=float(rng.choice([0.0, 0.3])))
         planes[2] = rng.uniform(0.0, 0.3, planes[2].shape).astype(np.float32)         # competitors' Laplace location ...
