@@ -40,3 +40,4 @@ print(f"non-binding rows/env-day {v[7] / max(v[4], 1):.2f}, their resolve (= cha
 print(f"env-days/step {v[4] / steps:.0f}  rows/env-day {v[5] / max(v[4], 1):.2f}  walker calls/row {v[6] / max(v[5], 1):.2f}")
 for i, n in enumerate(["passA", "resolve (incl. chain)", "  chain + its barrier", "passB"]):
     print(f"{n:24s} {v[i] * 10 / max(v[5], 1) / 1e3:8.2f} us/row   {v[i] * 10e-9 * 1e3 / steps:8.2f} block-ms/step")
+eng.walk_stats()      # (timing build: prints the phase sums of k_step_click_walk and k_step_rest_of_day to stderr)
