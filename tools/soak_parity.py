@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle soak: random shapes, keyword laws, budgets, drift, autoreset; every step compared
-bit for bit.  Usage: python tools/soak_parity.py [seconds] [seed] [explicit | general]"""
+bit for bit.  Usage: python tools/soak_parity.py [seconds] [seed] [explicit | general | lists]
+(lists: IMPLICIT engines of at most 256 keywords stepped 6-14 times with budgets that keep binding, so that the click lists of
+k_step_click_walk - which an env starts on its third binding day - and k_step_rest_of_day are what is compared most of the time)"""
 import sys
 import time
 
@@ -15,6 +17,7 @@ budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 explicit = len(sys.argv) > 3 and sys.argv[3] == "explicit"      # the default-constructor (ExplicitKeyword) model
 general = len(sys.argv) > 3 and sys.argv[3] == "general"        # the default ImplicitKeyword (bidder pools, top-(w+n) clearing)
+lists = len(sys.argv) > 3 and sys.argv[3] == "lists"
 t0 = time.time()
 cases = steps = reruns = 0
 last_report = t0
@@ -25,6 +28,9 @@ while time.time() - t0 < budget_s:
     N = int(rng.integers(1, 9))
     K = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 255, 256, 257, 300, 511, 700, 1024, 1100]))
     mv = float(rng.choice([0, 1, 5, 16, 40, 128, 600]))
+    if lists:
+        K = int(rng.choice([7, 64, 100, 200, 256]))
+        mv = float(rng.choice([16, 40, 128, 300]))
     planes = H.implicit_params(N, K, seed=int(rng.integers(1 << 30)), mean_volume=mv, cvr=float(rng.uniform(0, 1)),
                                no_vol_prob=float(rng.choice([0.0, 0.3, 0.9])))
     if rng.random() < 0.3:
@@ -56,9 +62,15 @@ while time.time() - t0 < budget_s:
     e.reset(seeds=rng.integers(0, 1 << 40, N).astype(np.uint64))
     extra = dict(max_bidders=pool[0], participation_rate=pool[1], num_winners=pool[2]) if general else {}
     o = H.mirror_oracle(e, planes, drift_on=drift, drift=(0.1, 0.2, 0.3), max_days=max_days, loss_threshold=loss, auto_reset=auto, **extra)
-    for s in range(int(rng.integers(1, 6))):
+    day_cost = None          # (lists) what an unconstrained day of this engine costs, per env: budgets are set relative to it
+    for s in range(int(rng.integers(6, 15)) if lists else int(rng.integers(1, 6))):
         bids = o.sample_bids(float(rng.uniform(0.01, 0.6)), float(rng.uniform(0.6, 2.0)))
         budget = rng.choice([1e9, 500.0, 50.0, 5.0, 0.3, 0.0], size=N).astype(np.float32)
+        if lists and day_cost is not None:
+            frac = rng.choice([0.02, 0.2, 0.5, 0.8, 0.97, 3.0], size=N, p=[0.15, 0.25, 0.25, 0.2, 0.1, 0.05])
+            budget = np.maximum(day_cost * frac, 0.01).astype(np.float32)
+        elif lists:
+            budget = np.full(N, 1e9, dtype=np.float32)
         got, ref = e.step(bids, budget), o.step(bids, budget)
         try:
             H.assert_step_equal(got, ref, implicit=not (explicit or general))
@@ -66,10 +78,16 @@ while time.time() - t0 < budget_s:
             print("MISMATCH", dict(N=N, K=K, mv=mv, drift=drift, auto=auto, step=s, budget=budget.tolist()))
             raise
         reruns += int((ref["cost_cents"].sum(axis=1) >= np.rint(budget.astype(np.float64) * 100)).sum())
+        if lists and day_cost is None:
+            day_cost = np.maximum(ref["cost_cents"].sum(axis=1) / 100.0, 1.0)
         steps += 1
     if drift:
         o.materialize_drift()
         assert np.array_equal(e.get_all_params(), o.params)
+    if lists:
+        walk = e.walk_stats().tolist()          # (the device's counters: cumulative over the process)
     e.close()
     cases += 1
+if lists:
+    print(f"k_step_click_walk: {walk[0]} env-days walked ({walk[2]} of them with a campaign stop), {walk[1]} lists overflowed, {walk[3]} other hand-overs")
 print(f"soak ok: {cases} engines, {steps} steps, {reruns} budget-bound env-steps, {time.time() - t0:.0f} s")
