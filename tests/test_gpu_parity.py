@@ -749,6 +749,9 @@ def test_ideal_profit_matches_host_restatement(amd):
     from oracle import capi as orc, ref_numpy as rn
     N, K, n = 2, 6, 2048
     planes = H.implicit_params(N, K, seed=31)
+    planes[0, 0, 1] = 0.0          # keywords whose profit is zero at every bid (no volume / no clicks / no margin): the kernel skips
+    planes[4, 0, 2] = 0.0          # their sampling - the reference formula gives the same 0
+    planes[5, 1, 3] = 0.0
     e = amd.StepEngine(N, K, seed=5)
     e.set_all_params(planes)
     e.reset()
