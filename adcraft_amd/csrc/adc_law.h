@@ -35,8 +35,10 @@ namespace adc {
 //           call (j, ST_CONV)      = {conversion, revenue} words (x,y), consumed only for a paid click.
 // EXPLICIT: call (j, ST_AUCTION)   = {impression, cost, click, conversion}; (j, ST_XREV).x = revenue;
 //           (t, ST_XPHANTOM)       = {click, conversion, revenue} of the zero-impression phantom of cell t.
-// GENERAL (the reference's default ImplicitKeyword; stream revision 3 for this model): call (64 t + b/4, ST_GBIDDERS) word b%4 =
-//           participation coin of bidder b in sub-timestep t; call (j, ST_GBID) = the exponential spacings of the TOP bids of
+// GENERAL (the reference's default ImplicitKeyword; stream revisions 3 and 4 for this model): call (t/4, ST_GBIDDERS) word t%4 =
+//           the uniform that the bidder count of sub-timestep t is read off (general_bidder_law: Binomial by inversion); where
+//           that is not applicable, call (64 t + b/4, ST_GBIDDERS) word b%4 = participation coin of bidder b, as before;
+//           call (j, ST_GBID) = the exponential spacings of the TOP bids of
 //           auction j, highest first (top_laplace_bids: order statistics instead of one draw per bidder);
 //           call (j, ST_GCLICK) = {click, conversion, revenue} words of auction j.
 enum Stage : uint32_t { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8, ST_AGENT = 9,
@@ -728,6 +730,64 @@ ADC_HD float synthetic_bid(uint32_t w, float lo, float hi)
 {
     const float b = fma32(hi - lo, unit_closed24(w), lo);
     return __builtin_rintf(b * 100.0f) / 100.0f;
+}
+
+// ---- IMPLICIT_GENERAL, stream revision 4: the number of bidders of a call by INVERSION ------------------------------------
+// The reference draws, per keyword and sub-timestep, which of the max_bidders competitors take part (rng.random(n) <= rate,
+// synthetic_kw_classes.py:610-621) and only ever uses how many do: B ~ Binomial(max_bidders, rate).  Instead of max_bidders coins
+// (8 Philox calls at the default 30) B is read off ONE uniform by walking the pmf up from 0: pmf(0) = q^n, pmf(b + 1) =
+// pmf(b) (n - b) / (b + 1) p / q, in float32 built from the deterministic log / exp (so the oracle reproduces every bit; the
+// 23-bit uniform resolves probabilities to 1.2e-7).  Applicable while q^n is a normal float and 0 < p < 1; otherwise the coins.
+struct BidderLaw {
+    float pmf0, ratio;      // q^n and p / q; pmf0 = 0: not applicable (use the coins)
+    int n;
+};
+constexpr int kBidderTable = 128;     // pools up to 127 bidders go by the table (bidders_from_table); the default is 30
+ADC_HD BidderLaw general_bidder_law(int max_bidders, float rate)
+{
+    BidderLaw L{0.0f, 0.0f, max_bidders};
+    if (!(rate > 0.0f && rate < 1.0f) || max_bidders < 1 || max_bidders >= kBidderTable) return L;
+    const float q = 1.0f - rate;
+    const float lp = (float)max_bidders * det_log(q);
+    if (!(lp > -60.0f)) return L;
+    L.pmf0 = det_exp(lp);
+    L.ratio = rate / q;
+    return L;
+}
+ADC_HD int bidders_from_word(uint32_t w, const BidderLaw &L)
+{
+    const float u = unit_open23(w);
+    float pmf = L.pmf0, cdf = L.pmf0;
+    int b = 0;
+    while (u > cdf && b < L.n) {
+        pmf = pmf * ((float)(L.n - b) / (float)(b + 1)) * L.ratio;
+        cdf = cdf + pmf;
+        ++b;
+    }
+    return b;
+}
+
+// The same walk, done once: cdf[b] = P(B <= b) for b = 0 .. n - 1 exactly as bidders_from_word accumulates it, and the count
+// read off by bisection (the sums are non-decreasing) - what the keyword-parallel kernels use: the walk's float division per
+// step, at the wave's longest trip count, cost as much as the eight Philox calls it replaced.
+ADC_HD void fill_bidder_cdf(float *cdf, const BidderLaw &L)
+{
+    float pmf = L.pmf0, c = L.pmf0;
+    for (int b = 0; b < L.n; ++b) {
+        cdf[b] = c;
+        pmf = pmf * ((float)(L.n - b) / (float)(b + 1)) * L.ratio;
+        c = c + pmf;
+    }
+}
+ADC_HD int bidders_from_table(uint32_t w, const float *cdf, int n)
+{
+    const float u = unit_open23(w);
+    int lo = 0, hi = n;                 // the first b in [0, n) with u <= cdf[b]; n if there is none
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (u > cdf[mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 // ---- IMPLICIT_GENERAL (the reference's default ImplicitKeyword), stream revision 3: the top bids as ORDER STATISTICS --------

@@ -50,7 +50,9 @@ enum { P_VOL_MEAN = 0, P_VOL_STD, P_A, P_B, P_BCTR, P_SCTR, P_REV_MEAN, P_REV_ST
 /* P_A / P_B: IMPLICIT cost_loc / cost_scale (Laplace), EXPLICIT imp_intercept / imp_slope */
 enum { ST_VOL = 0, ST_AUCTION = 1, ST_DRIFT = 2, ST_XPHANTOM = 3, ST_XREV = 4, ST_ACTION = 5, ST_METRIC = 6, ST_CONV = 7, ST_KEYGEN = 8,
        ST_AGENT = 9, ST_GBIDDERS = 10, ST_GBID = 11, ST_GCLICK = 12 };
-/* IMPLICIT_GENERAL (the reference's default ImplicitKeyword; stream revision 3 for this model): call (64 t + b/4, ST_GBIDDERS)
+/* IMPLICIT_GENERAL (the reference's default ImplicitKeyword; stream revisions 3 and 4 for this model; revision 4: call (t/4,
+ * ST_GBIDDERS) word t%4 = the uniform the bidder count of sub-timestep t is read off, orc_bidders_from_word; where that is not
+ * applicable, as in revision 3:) call (64 t + b/4, ST_GBIDDERS)
  * word b%4 = participation coin of bidder b in sub-timestep t; call (j, ST_GBID) = the exponential spacings of the top bids of
  * auction j, highest first (orc_top_laplace_bids); call (j, ST_GCLICK) = {click, conversion, revenue} words of auction j. */
 /* Stream layout (revision 2): call (0, ST_VOL, k/4) holds the volume words of keywords 4(k/4)..+3 (word k%4).
@@ -406,6 +408,34 @@ ORC_API float orc_explicit_cost_from_word(uint32_t w, float bid)
     return fminf(fmaxf(v, 0.0f), 4.4f);
 }
 
+/* IMPLICIT_GENERAL, stream revision 4: the number of bidders of a call, Binomial(max_bidders, rate) (synthetic_kw_classes.py:610-621:
+ * rng.random(n) <= rate, of which only the count is used), read off one uniform by walking the pmf up from 0 in float32:
+ * pmf(0) = q^n, pmf(b + 1) = pmf(b) (n - b) / (b + 1) p / q.  pmf0 = 0: not applicable (rate outside (0, 1) or q^n too small) -
+ * then the max_bidders coins of revision 3 are drawn. */
+ORC_API void orc_bidder_law(int32_t max_bidders, float rate, float *pmf0, float *ratio)
+{
+    *pmf0 = 0.0f;
+    *ratio = 0.0f;
+    if (!(rate > 0.0f && rate < 1.0f) || max_bidders < 1 || max_bidders >= 128) return;      /* (the engine keeps the sums in a table of 128) */
+    const float q = 1.0f - rate;
+    const float lp = (float)max_bidders * orc_det_logf(q);
+    if (!(lp > -60.0f)) return;
+    *pmf0 = orc_det_expf(lp);
+    *ratio = rate / q;
+}
+ORC_API int32_t orc_bidders_from_word(uint32_t w, int32_t n, float pmf0, float ratio)
+{
+    const float u = u23(w);
+    float pmf = pmf0, cdf = pmf0;
+    int32_t b = 0;
+    while (u > cdf && b < n) {
+        pmf = pmf * ((float)(n - b) / (float)(b + 1)) * ratio;
+        cdf = cdf + pmf;
+        ++b;
+    }
+    return b;
+}
+
 /* IMPLICIT_GENERAL, stream revision 3: the top k = min(B, top) of B iid Laplace(loc, |scale|) bids (rng.laplace,
  * adcraft/synthetic_kw_classes.py:681-686), descending, as order statistics: t_1 = E_1 / B, t_2 = t_1 + E_2 / (B - 1), ... with
  * E_i = -log(u_i) are -log of the top uniform order statistics (Renyi); the Laplace quantile at p = exp(-t) is
@@ -676,12 +706,20 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                 int32_t B;
                 if (use_tape) B = tape->x_impressions[tape->cur_ximp++];
                 else {
-                    const uint64_t t_part = orc_bernoulli_threshold(c->participation_rate);
-                    B = 0;
-                    for (int32_t b = 0; b < c->max_bidders; ++b) {
+                    float pmf0, ratio;
+                    orc_bidder_law(c->max_bidders, c->participation_rate, &pmf0, &ratio);
+                    if (pmf0 > 0.0f) {
                         uint32_t w[4];
-                        draw(key, (uint32_t)(64 * t + (b >> 2)), ST_GBIDDERS, (uint32_t)k, tick, w);
-                        if ((uint64_t)w[b & 3] < t_part) ++B;
+                        draw(key, (uint32_t)(t >> 2), ST_GBIDDERS, (uint32_t)k, tick, w);
+                        B = orc_bidders_from_word(w[t & 3], c->max_bidders, pmf0, ratio);
+                    } else {
+                        const uint64_t t_part = orc_bernoulli_threshold(c->participation_rate);
+                        B = 0;
+                        for (int32_t b = 0; b < c->max_bidders; ++b) {
+                            uint32_t w[4];
+                            draw(key, (uint32_t)(64 * t + (b >> 2)), ST_GBIDDERS, (uint32_t)k, tick, w);
+                            if ((uint64_t)w[b & 3] < t_part) ++B;
+                        }
                     }
                 }
                 const int32_t width = B > top ? B : top;

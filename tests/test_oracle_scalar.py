@@ -245,6 +245,46 @@ def test_cents_to_dollars_is_the_ieee_quotient():
     assert L.orc_check_div100f(0, 1 << 24) == 0            # cents_to_dollars_f32: every |cents| below 2^24, both signs
 
 
+def test_bidder_count_by_inversion_is_binomial():
+    """IMPLICIT_GENERAL, stream revision 4 (orc_bidders_from_word / adc_law.h bidders_from_word): the number of participating
+    competitors of a call - the reference draws max_bidders coins (`rng.random(n) <= rate`, synthetic_kw_classes.py:610-621) and uses
+    their count - is read off one uniform by inversion.  Chi-square against scipy's Binomial pmf for several pools and rates, the
+    exact answers at the ends of the uniform's range, and the cases it declines (rate 0 or 1, a pool whose q^n underflows)."""
+    import ctypes as C
+    from scipy import stats
+    L = orc.lib()
+    L.orc_bidder_law.argtypes = [C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_bidder_law.restype = None
+    L.orc_bidders_from_word.argtypes = [C.c_uint32, C.c_int32, C.c_float, C.c_float]
+    L.orc_bidders_from_word.restype = C.c_int32
+
+    def law(n, p):
+        a, b = C.c_float(), C.c_float()
+        L.orc_bidder_law(n, p, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    rng = np.random.default_rng(77)
+    for n, p in [(30, 0.6), (3, 0.4), (70, 0.5), (1, 0.2), (9, 0.97), (120, 0.1)]:
+        pmf0, ratio = law(n, p)
+        assert pmf0 > 0
+        words = rng.integers(0, 2**32, 200_000, dtype=np.uint64)
+        got = np.array([L.orc_bidders_from_word(int(w), n, pmf0, ratio) for w in words])
+        assert got.min() >= 0 and got.max() <= n
+        expected = stats.binom.pmf(np.arange(n + 1), n, p) * len(words)
+        keep = expected >= 5                                    # pool the thin tails
+        obs = np.bincount(got, minlength=n + 1).astype(float)
+        o = np.append(obs[keep], obs[~keep].sum())
+        e = np.append(expected[keep], expected[~keep].sum())
+        if e[-1] == 0:
+            o, e = o[:-1], e[:-1]
+        chi2 = ((o - e) ** 2 / e).sum()
+        assert chi2 < stats.chi2.ppf(1 - 1e-6, len(e) - 1), (n, p, chi2)
+        assert L.orc_bidders_from_word(0, n, pmf0, ratio) == 0 or pmf0 < 6e-8          # the smallest uniform: nobody, unless P(0) is below it
+        assert L.orc_bidders_from_word(0xFFFFFFFF, n, pmf0, ratio) >= min(n, int(stats.binom.ppf(1 - 1e-6, n, p)))
+    for n, p in [(30, 0.0), (30, 1.0), (250, 0.6), (128, 0.5), (100, 0.999), (0, 0.5)]:  # not applicable: the coins of revision 3 are drawn
+        assert law(n, p)[0] == 0.0
+
+
 def test_top_laplace_bids_have_the_joint_law_of_the_sorted_draws():
     """IMPLICIT_GENERAL, stream revision 3 (orc_top_laplace_bids / adc_law.h top_laplace_bids): the top (w + n) bids of an auction
     drawn directly as order statistics must be distributed as the top of B sorted rng.laplace(loc, scale) draws
