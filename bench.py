@@ -34,7 +34,7 @@ BYTES_PER_ENV = 26
 MAX_DAYS = 60
 # the three intervals between the engine's HIP events; the IMPLICIT kernels add their metric sums in their own output phase, so
 # the third interval holds no kernel here (what it shows is the cost of recording an event pair)
-KERNEL_NAMES = ("k_step_implicit_fast", "k_tail_or_flag + the budget-exact kernels (k_step_click_walk, k_step_exact_rows, k_step_rest_of_day)",
+KERNEL_NAMES = ("k_step_implicit_fast", "k_tail_or_flag + the budget-exact kernels (k_step_click_walk, k_step_exact_rows, k_step_rest_of_day, k_rest_walk)",
                 "(no kernel: event-record overhead)")
 # the reference's own Python loop, unmodified, on this keyword law: measured in the BUILD container (tools/time_reference_python.py,
 # one Xeon core @ 2.1 GHz, stand-ins for the two modules that cannot be imported there) - never on the GPU box, where

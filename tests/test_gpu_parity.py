@@ -235,6 +235,23 @@ def test_click_walk_matches_oracle(amd, monkeypatch, case):
     e.close()
 
 
+@pytest.mark.parametrize("case", ["lists", "few_marks_then_table", "table_only", "one_kernel"])
+@pytest.mark.parametrize("budget", [700.0, 40.0, 0.4])
+def test_rest_of_day_pair_matches_oracle(amd, monkeypatch, case, budget):
+    """K <= 256: k_step_rest_of_day<true> hands the cells that may hold an affordable click to k_rest_walk as an ordered list
+    (up to 1024 per env), beyond that as the whole table; ADCRAFT_REST_SPLIT=0 keeps both halves in one kernel.  All four give
+    the oracle's days, campaigns that stop included (budget 0.4).  In k_rest_walk every lane resolves its own cell; cells of
+    many auctions or clicks go through the whole wavefront (the third shape)."""
+    monkeypatch.setenv("ADCRAFT_CLICK_WALK", "0")            # every binding day goes rows -> rest of day
+    if case == "few_marks_then_table": monkeypatch.setenv("ADCRAFT_REST_MARKS", "3")
+    if case == "table_only": monkeypatch.setenv("ADCRAFT_REST_MARKS", "0")
+    monkeypatch.setenv("ADCRAFT_REST_SPLIT", "0" if case == "one_kernel" else "1")       # (the default splits from 1024 envs on)
+    for N, K, seed, vol in ((5, 256, 51, 60), (3, 77, 52, 60), (2, 40, 53, 2500)):     # (cells of 2-3 auctions; of a hundred)
+        planes = H.implicit_params(N, K, seed=seed, mean_volume=vol)
+        n = _run_vs_oracle(amd, N, K, planes, steps=3, budget=budget, bid_lo=0.4, bid_hi=1.2)
+        assert n > 0
+
+
 def test_mixed_binding_and_not(amd):
     """some envs hit the budget, others do not, in the same launch"""
     N, K = 8, 64
