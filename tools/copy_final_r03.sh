@@ -10,7 +10,8 @@ cp $F/binding.txt $P/r03_final_binding_budget.txt; cp $F/binding_wide.txt $P/r03
 cp $F/ideal_step.txt $P/r03_final_ideal_step.txt; cp $F/closed_loop.txt $P/r03_final_closed_loop.txt; cp $F/sparse_floor.txt $P/r03_final_sparse_floor.txt
 cp $F/vector_env.txt $P/r03_final_vector_env.txt; cp $F/small_env.txt $P/r03_final_small_env.txt
 cp $F/binding_ctr.txt $P/r03_final_binding_click_walk.txt; cp $F/binding_wide_float.txt $P/r03_final_binding_wide_float_models.txt
-(for f in soak_implicit soak_implicit_sparse_kernel soak_explicit soak_general; do echo "== $f"; tail -n 6 $F/$f.txt; done) > $P/r03_final_soak_parity.txt
+for b in 1000 10; do cp $F/kernel_stats_budget$b.csv $P/r03_final_kernel_stats_cfg2_budget$b.csv; done
+(for f in soak_implicit soak_implicit_sparse_kernel soak_implicit_rest_pair soak_explicit soak_general; do echo "== $f"; tail -n 6 $F/$f.txt; done) > $P/r03_final_soak_parity.txt
 python3 - <<'PY'
 import json
 out = {}

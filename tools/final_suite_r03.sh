@@ -31,5 +31,7 @@ timeout -k 10 300 python3 tools/soak_parity.py 120 201 > $OUT/soak_implicit.txt 
 ADCRAFT_FAST_VARIANT=2 ADCRAFT_FAST_TILE_KW=256 timeout -k 10 300 python3 tools/soak_parity.py 120 204 > $OUT/soak_implicit_sparse_kernel.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 100 202 explicit > $OUT/soak_explicit.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 100 203 general > $OUT/soak_general.txt 2>&1 || exit 1
-tail -n1 $OUT/soak_implicit.txt; tail -n1 $OUT/soak_implicit_sparse_kernel.txt; tail -n1 $OUT/soak_explicit.txt; tail -n1 $OUT/soak_general.txt
+ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 80 205 > $OUT/soak_implicit_rest_pair.txt 2>&1 || exit 1
+for b in 1000 10; do ADCRAFT_CLICK_WALK=0 bash tools/kt_budget.sh $b > /dev/null 2>&1 || exit 1; cp gpurun_out/kt_b$b/kt_kernel_stats.csv $OUT/kernel_stats_budget$b.csv; done
+tail -n1 $OUT/soak_implicit.txt; tail -n1 $OUT/soak_implicit_rest_pair.txt; tail -n1 $OUT/soak_implicit_sparse_kernel.txt; tail -n1 $OUT/soak_explicit.txt; tail -n1 $OUT/soak_general.txt
 echo done
