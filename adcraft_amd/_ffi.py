@@ -46,6 +46,7 @@ class Tape(C.Structure):
 
 
 _lib = None
+ABI_VERSION, STREAM_REVISION = 4, 4           # include/adcraft_engine.h ADC_ABI_VERSION, ADC_STREAM_REVISION
 
 
 def library_path():
@@ -75,6 +76,7 @@ def lib():
     vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
     sig = {
         "adc_abi_version": ([], C.c_int),
+        "adc_stream_revision": ([], C.c_int),
         "adc_device_count": ([vp], C.c_int),
         "adc_engine_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
         "adc_engine_destroy": ([vp], None),
@@ -134,6 +136,7 @@ def lib():
         "adc_engine_metrics_akncp_ncp": ([vp, f64, vp, vp], C.c_int),
         "adc_engine_bid_curves_contenders": ([vp, vp, vp, C.POINTER(i32)], C.c_int),
         "adc_engine_outcomes_replay": ([vp, i32, i32, vp, f32, i64, vp, vp, vp, vp, C.POINTER(i64), vp], C.c_int),
+        "adc_engine_outcomes_replay_tape": ([vp, i32, vp, f32, C.POINTER(Tape), i64, vp, vp, vp, vp, C.POINTER(i64), vp], C.c_int),
         "adc_nth_price_auction": ([C.c_int, f64, vp, i32, i32, i32, i32, C.POINTER(i32), vp, vp], C.c_int),
         "adc_sigmoid": ([f64, f64, f64], f64),
         "adc_clamp": ([f64, f64, f64], f64),
@@ -160,8 +163,9 @@ def lib():
         fn = getattr(L, name)      # AttributeError here = the .so does not export what the header declares
         fn.argtypes = args
         fn.restype = res
-    if L.adc_abi_version() != 3:
-        raise EngineError("libadcraft_hip.so ABI version mismatch")
+    if L.adc_abi_version() != ABI_VERSION or L.adc_stream_revision() != STREAM_REVISION:
+        raise EngineError(f"{path}: ABI version {L.adc_abi_version()} / stream revision {L.adc_stream_revision()}, this package "
+                          f"expects {ABI_VERSION} / {STREAM_REVISION} (a stale build?)")
     _lib = L
     return L
 

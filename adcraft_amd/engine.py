@@ -229,10 +229,12 @@ class StepEngine:
         _check_overflow(self._overflow)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
-    def outcomes_replay(self, env, bids_k, budget, steps_back=1):
+    def outcomes_replay(self, env, bids_k, budget, steps_back=1, tape=None):
         """the paid clicks of one step of env `env` (steps_back = 1: its last), one by one, in the reference's order
         (adc_engine_outcomes_replay): dict of keyword, timestep, cost (dollars), revenue (dollars, -1 = no conversion) and
-        share_volume [K].  An earlier step can be replayed while drift is off and nothing has changed the parameters since."""
+        share_volume [K].  An earlier step can be replayed while drift is off and nothing has changed the parameters since.
+        With a ReplayTape the step is the one the tape describes (adc_engine_outcomes_replay_tape: parity against the reference's
+        recorded BiddingOutcomes); nothing of the engine's state is touched either way."""
         K = self.num_keywords
         bids = np.ascontiguousarray(bids_k, dtype=np.float32).reshape(K)
         share = np.zeros(K, np.int32)
@@ -241,8 +243,13 @@ class StepEngine:
         while True:
             kw, ts = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
             cost, rev = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
-            check(self._lib.adc_engine_outcomes_replay(self._h, int(env), int(steps_back), bids.ctypes.data, float(budget), cap, kw.ctypes.data, ts.ctypes.data,
-                                                       cost.ctypes.data, rev.ctypes.data, C.byref(n), share.ctypes.data))
+            if tape is None:
+                check(self._lib.adc_engine_outcomes_replay(self._h, int(env), int(steps_back), bids.ctypes.data, float(budget), cap, kw.ctypes.data,
+                                                           ts.ctypes.data, cost.ctypes.data, rev.ctypes.data, C.byref(n), share.ctypes.data))
+            else:
+                check(self._lib.adc_engine_outcomes_replay_tape(self._h, int(env), bids.ctypes.data, float(budget), C.byref(tape.struct), cap,
+                                                                kw.ctypes.data, ts.ctypes.data, cost.ctypes.data, rev.ctypes.data, C.byref(n),
+                                                                share.ctypes.data))
             if n.value <= cap:
                 m = n.value
                 return dict(keyword=kw[:m], timestep=ts[:m], cost=cost[:m], revenue=rev[:m], share_volume=share)

@@ -20,6 +20,7 @@ What differs from the reference, on purpose (DESIGN.md "quirks"):
   * only updater_mask None or all-True is supported (the only masks the reference's configs use; a
     partial mask mis-aligns coefficients in the reference, gymnasium_kw_env.py:136-144).
 """
+import weakref
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -145,6 +146,7 @@ class BiddingSimulation(_EnvBase):
         self._params_dirty = False
         self._serial = 0                  # steps taken since the stream was last (re)keyed or the parameters last changed
         self._epoch = 0                   # bumped by whatever ends the replayability of earlier steps
+        self._last_outcomes = None        # weak reference to the last step's unread info["bidding_outcomes"]
         self.current_day = 0
         self.cumulative_profit = 0.0
         if updater_mask is not None:
@@ -175,14 +177,27 @@ class BiddingSimulation(_EnvBase):
             return
         assert len(self.updater_mask) == self.num_keywords
         assert self._engine is not None, "reset required, need to generate keywords to bid on"
+        self._settle_last_outcomes()
         self._engine.update_keywords()
         self._params_dirty = True
         self._epoch += 1
+
+    def _settle_last_outcomes(self):
+        """With drift on, the last step's update_keywords() is still pending on the device and its per-click lists are regenerated
+        from the parameters that step ran with.  Whatever is about to write the drifted parameters into the planes (reading
+        keyword_params, update_keywords()) first formats the last step's info["bidding_outcomes"] - if that info dict is still
+        alive and unread - so the text a caller reads afterwards is that step's own."""
+        ref = self._last_outcomes
+        lazy = ref() if ref is not None else None
+        if lazy is not None and self._drift_on():
+            str(lazy)
+        self._last_outcomes = None
 
     # ------------------------------------------------------------------ keyword state
     @property
     def keyword_params(self):
         if self._params_dirty and self._engine is not None:
+            self._settle_last_outcomes()
             planes = self._engine.get_all_params()[:, 0, :].astype(np.float64)
             for k, p in enumerate(self._params_host):
                 p[0] = (float(planes[P_VOL_MEAN, k]), p[0][1])
@@ -283,6 +298,7 @@ class BiddingSimulation(_EnvBase):
         self._serial += 1
         serial, epoch = self._serial, self._epoch
         outcomes = _Lazy(lambda: self._outcomes_text(serial, epoch, bids, rounded.astype(np.float32), budget_used, snap))
+        self._last_outcomes = weakref.ref(outcomes)
         info = {
             "bids": bids,
             "bidding_outcomes": outcomes,
@@ -311,7 +327,11 @@ class BiddingSimulation(_EnvBase):
         back = self._serial - serial + 1
         replayable = (self._engine is not None and epoch == self._epoch and (back == 1 or not self._drift_on()))
         if replayable:
-            return self._repr_outcomes(bids, obs, self._engine.outcomes_replay(0, bids_f32, budget_used, steps_back=back))
+            try:
+                clicks = self._engine.outcomes_replay(0, bids_f32, budget_used, steps_back=back)
+            except AssertionError:          # ADC_ESTATE: the engine itself says this step's clicks are gone (e.g. its drift was applied)
+                clicks = None
+            return self._repr_outcomes(bids, obs, clicks)
         return self._repr_outcomes(bids, obs, None)
 
     @staticmethod
@@ -323,7 +343,6 @@ class BiddingSimulation(_EnvBase):
             x = float(x)
             return str(int(x)) if x == int(x) and abs(x) < 1e16 else repr(x)
 
-        K = len(bids)
         rows = []
         if clicks is None:                                  # expired (see _outcomes_text): the step's totals only
             for k, b in enumerate(bids):
@@ -333,33 +352,11 @@ class BiddingSimulation(_EnvBase):
                             f"'sellside_conversions': {int(obs['sellside_conversions'][k])}, 'revenues': [{r!r}], "
                             f"'profit': {disp(r - c)}, 'per_click': 'expired'" + "}")
             return "[" + ", ".join(rows) + "]"
-        by_kw = [[] for _ in range(K)]
-        for i in range(len(clicks["keyword"])):
-            by_kw[int(clicks["keyword"][i])].append(i)
-        for k, b in enumerate(bids):
-            idx = by_kw[k]
-            costs = [float(clicks["cost"][i]) for i in idx]
-            rpc = [max(float(clicks["revenue"][i]), 0.0) for i in idx]
-            revenues = [float(clicks["revenue"][i]) for i in idx if clicks["revenue"][i] >= 0]
-            profit, t_prev, cell_r, cell_c = 0.0, None, 0.0, 0.0
-            for i in idx:                                   # per sub-timestep: sum(revenues) - sum(costs), then added up
-                t = int(clicks["timestep"][i])
-                if t != t_prev and t_prev is not None:
-                    profit += cell_r - cell_c
-                    cell_r = cell_c = 0.0
-                t_prev = t
-                cell_c += float(clicks["cost"][i])
-                if clicks["revenue"][i] >= 0:
-                    cell_r += float(clicks["revenue"][i])
-            if t_prev is not None:
-                profit += cell_r - cell_c
-            imp = int(obs["impressions"][k])
-            vol = int(clicks["share_volume"][k])
-            share = imp / vol if vol > 0 else 0.0
-            rows.append("{" + f"'bid': {disp(b)}, 'impressions': {imp}, 'impression_share': {disp(share)}, "
-                        f"'buyside_clicks': {int(obs['buyside_clicks'][k])}, 'costs': {costs!r}, "
-                        f"'sellside_conversions': {int(obs['sellside_conversions'][k])}, 'revenues': {revenues!r}, "
-                        f"'revenues_per_cost': {rpc!r}, 'profit': {disp(profit)}" + "}")
+        for o in combined_outcomes(bids, obs, clicks):
+            rows.append("{" + f"'bid': {disp(o['bid'])}, 'impressions': {o['impressions']}, 'impression_share': {disp(o['impression_share'])}, "
+                        f"'buyside_clicks': {o['buyside_clicks']}, 'costs': {o['costs']!r}, "
+                        f"'sellside_conversions': {o['sellside_conversions']}, 'revenues': {o['revenues']!r}, "
+                        f"'revenues_per_cost': {o['revenues_per_cost']!r}, 'profit': {disp(o['profit'])}" + "}")
         return "[" + ", ".join(rows) + "]"
 
     def render(self) -> Optional[str]:
@@ -371,6 +368,43 @@ class BiddingSimulation(_EnvBase):
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+
+
+def combined_outcomes(bids, obs, clicks):
+    """The step's combined BiddingOutcomes (bidding_simulation.py:10-38), one dict per keyword, from the regenerated click records
+    (StepEngine.outcomes_replay: keyword, timestep, cost, revenue | -1 per paid click in the reference's order, share_volume):
+    'costs' / 'revenues' / 'revenues_per_cost' are the click lists as combine_outcomes concatenates them (:138-141), 'profit' adds
+    each sub-timestep's sum(revenues) - sum(costs) in order (:117,136-137), 'impression_share' = impressions over the auctions of
+    the sub-timesteps that had an impression - the denominator combine_outcomes' np.round(impressions / impression_share) chain
+    ends up with (:128-145; a sub-timestep without impressions drops out of it)."""
+    K = len(bids)
+    by_kw = [[] for _ in range(K)]
+    for i in range(len(clicks["keyword"])):
+        by_kw[int(clicks["keyword"][i])].append(i)
+    out = []
+    for k, b in enumerate(bids):
+        idx = by_kw[k]
+        costs = [float(clicks["cost"][i]) for i in idx]
+        rpc = [max(float(clicks["revenue"][i]), 0.0) for i in idx]
+        revenues = [float(clicks["revenue"][i]) for i in idx if clicks["revenue"][i] >= 0]
+        profit, t_prev, cell_r, cell_c = 0.0, None, 0.0, 0.0
+        for i in idx:                                   # per sub-timestep: sum(revenues) - sum(costs), then added up
+            t = int(clicks["timestep"][i])
+            if t != t_prev and t_prev is not None:
+                profit += cell_r - cell_c
+                cell_r = cell_c = 0.0
+            t_prev = t
+            cell_c += float(clicks["cost"][i])
+            if clicks["revenue"][i] >= 0:
+                cell_r += float(clicks["revenue"][i])
+        if t_prev is not None:
+            profit += cell_r - cell_c
+        imp = int(obs["impressions"][k])
+        vol = int(clicks["share_volume"][k])
+        out.append(dict(bid=float(b), impressions=imp, impression_share=imp / vol if vol > 0 else 0.0,
+                        buyside_clicks=int(obs["buyside_clicks"][k]), costs=costs,
+                        sellside_conversions=int(obs["sellside_conversions"][k]), revenues=revenues, revenues_per_cost=rpc, profit=profit))
+    return out
 
 
 def bidding_sim_creator(env_config: Dict) -> BiddingSimulation:

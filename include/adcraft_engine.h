@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define ADC_ABI_VERSION 3
+#define ADC_ABI_VERSION 4
+/* revision of the engine's own random stream (which variate lives at which Philox counter): results under a
+ * fixed seed - and golden streams recorded from an engine - are comparable only between libraries of the same revision.
+ * 2: IMPLICIT / EXPLICIT layout since round 2; 3, 4: IMPLICIT_GENERAL top bids as order statistics, bidder count by inversion */
+#define ADC_STREAM_REVISION 4
 
 typedef enum adc_status {
     ADC_OK = 0,
@@ -161,6 +165,7 @@ typedef struct adc_engine adc_engine;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
 int adc_abi_version(void);
+int adc_stream_revision(void);
 const char *adc_last_error(void);
 int adc_device_count(int *count);
 int adc_engine_create(const adc_config *cfg, adc_engine **out);
@@ -380,6 +385,12 @@ int adc_engine_metrics_akncp_ncp(adc_engine *e, double days, double *akncp_n, do
  * ADC_ESTATE when the step cannot be replayed. */
 int adc_engine_outcomes_replay(adc_engine *e, int32_t env, int32_t steps_back, const float *bids_k, float budget, int64_t capacity,
                                int32_t *keyword, int32_t *timestep, double *cost, double *revenue, int64_t *count, int32_t *share_volume_k);
+/* The same lists for a step given as a tape (parity mode: the variates the reference drew, adc_engine_step_replay): env `env`
+ * is walked over `tape` (its volumes, per-env start offsets and lengths as for adc_engine_step_replay; the end cursors are not
+ * written), read-only, with the keyword parameters as they stand.  This is how the lists are pinned against the reference's
+ * own BiddingOutcomes (adcraft/bidding_simulation.py:10-38,124-147; tests/golden/g3_*.json, g8_env_episodes.json). */
+int adc_engine_outcomes_replay_tape(adc_engine *e, int32_t env, const float *bids_k, float budget, const adc_tape *tape, int64_t capacity,
+                                    int32_t *keyword, int32_t *timestep, double *cost, double *revenue, int64_t *count, int32_t *share_volume_k);
 
 /* ---- standalone auction clearing (adcraft/synthetic_kw_helpers.py:116-180) ------------------------ */
 /* other_bids: host double [n_auctions][n_bidders]; placements/costs: host, capacity n_auctions.

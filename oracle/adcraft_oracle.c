@@ -543,6 +543,17 @@ typedef struct {
     uint8_t *terminated, *truncated;               /* [N] */
 } orc_out;
 
+/* the combined BiddingOutcomes of the step (bidding_simulation.py:10-38), optional: every paid click in the reference's order
+ * (sub-timestep, keyword, click) as it appends them to 'costs' / 'revenues_per_cost' (:97-104,113-115), and per keyword what
+ * combine_outcomes (:124-147) leaves in 'impression_share' and 'profit' - its arithmetic literally, the lossy volume
+ * re-derivation np.round(impressions / impression_share) included */
+typedef struct {
+    int64_t capacity, count;                       /* clicks that fit the lists / paid clicks of the step (may exceed capacity) */
+    int32_t *env, *keyword, *timestep;             /* [capacity] */
+    double *cost, *revenue;                        /* [capacity] dollars; revenue -1 = the click did not convert */
+    double *impression_share, *profit;             /* [N][K] */
+} orc_outcomes;
+
 typedef struct {             /* persistent per-env state, caller-owned */
     float *params;           /* [P_COUNT][N][K] */
     uint64_t *key;           /* [N] */
@@ -596,8 +607,29 @@ static void apply_drift_tape(const orc_config *c, orc_state *s, int env, const f
     }
 }
 
+/* one visited cell's outcome merged into the keyword's running result: combine_outcomes, bidding_simulation.py:124-147 */
+static void combine_cell(orc_outcomes *L, size_t idx, int32_t imps_before, int32_t cell_imps, int32_t cell_auctions, double cell_profit)
+{
+    /* simulate_epoch_of_bidding :88-91: the cell's own impression_share */
+    const double cell_share = cell_auctions > 0 ? (double)cell_imps / (double)cell_auctions : 0.0;
+    const double old_vol = imps_before < 1 ? 0.0 : rint((double)imps_before / L->impression_share[idx]);     /* :128-131 np.round */
+    const double next_vol = cell_imps < 1 ? 0.0 : rint((double)cell_imps / cell_share);                      /* :132-135 */
+    const double vol = old_vol + next_vol;                                                                   /* :141 */
+    L->profit[idx] += cell_profit;                                                                           /* :136-137 */
+    L->impression_share[idx] = vol > 0.0 ? (double)(imps_before + cell_imps) / vol : 0.0;                     /* :142-145 */
+}
+
+static void list_click(orc_outcomes *L, int env, int k, int t, double cost, double revenue)
+{
+    if (L->count < L->capacity) {
+        const int64_t i = L->count;
+        L->env[i] = env; L->keyword[i] = k; L->timestep[i] = t; L->cost[i] = cost; L->revenue[i] = revenue;
+    }
+    ++L->count;
+}
+
 static void step_env(const orc_config *c, orc_state *s, int env, const float *bids, float budget_in,
-                     orc_tape *tape, orc_out *o)
+                     orc_tape *tape, orc_out *o, orc_outcomes *L)
 {
     const int K = c->num_keywords;
     const size_t base = (size_t)env * K;
@@ -622,6 +654,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
         o->impressions[base + k] = o->clicks[base + k] = o->conversions[base + k] = 0;
         o->cost_cents[base + k] = o->revenue_cents[base + k] = 0;
         o->cost[base + k] = o->revenue[base + k] = 0.0;
+        if (L) L->impression_share[base + k] = L->profit[base + k] = 0.0;
     }
 
     const int64_t budget_cents = orc_budget_cents(budget_in);
@@ -647,7 +680,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                  * cost - is decided there by the float residue, and whether the campaign then stops changes the
                  * impressions of every later cell. */
                 const float loc = P(s, c, P_A, env, k), scale = P(s, c, P_B, env, k);
-                double budget = remaining_d, cell_sum_d = 0.0;
+                double budget = remaining_d, cell_sum_d = 0.0, cell_rev_d = 0.0;
                 int64_t cell_cost = 0;
                 int32_t wins = 0, paid = 0, convs = 0;
                 int broke = 0;
@@ -676,14 +709,18 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                         uint32_t w2[4] = {0, 0, 0, 0};
                         if (!use_tape) draw(key, j, ST_CONV, (uint32_t)k, tick, w2);
                         int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w2[0] < t_conv);
+                        int64_t rev = 0;
                         if (conv) {
-                            int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
-                                                   : orc_revenue_cents_tab(w2[1], rev_mu, rev_sd);
+                            rev = use_tape ? tape->rev_cents[tape->cur_rev++]
+                                           : orc_revenue_cents_tab(w2[1], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
+                            cell_rev_d += (double)rev / 100.0;       /* rust.sum_array(revenues), :117 */
                         }
+                        if (L) list_click(L, env, k, t, cost_d, conv ? (double)rev / 100.0 : -1.0);
                     } else broke = 1;                          /* break: no later click of this cell is paid */
                 }
+                if (L) combine_cell(L, base + k, o->impressions[base + k], wins, n, cell_rev_d - cell_sum_d);
                 if (use_tape) tape->cur_click += wins;
                 o->impressions[base + k] += wins;
                 o->clicks[base + k] += paid;
@@ -756,15 +793,18 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                         budget -= cost; cell_cost_sum += cost; ++paid;
                         o->cost[base + k] += cost;
                         const int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w3[1] < t_conv);
+                        int64_t rev = 0;
                         if (conv) {
-                            const int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++] : orc_revenue_cents_tab(w3[2], rev_mu, rev_sd);
+                            rev = use_tape ? tape->rev_cents[tape->cur_rev++] : orc_revenue_cents_tab(w3[2], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
                             cell_rev_c += rev;
                         }
+                        if (L) list_click(L, env, k, t, cost, conv ? (double)rev / 100.0 : -1.0);
                     } else broke = 1;
                 }
                 free(row);
+                if (L) combine_cell(L, base + k, o->impressions[base + k], imps, n, (double)cell_rev_c / 100.0 - cell_cost_sum);
                 if (use_tape) { tape->cur_xcost += (int64_t)B * n; tape->cur_click += imps; }
                 o->impressions[base + k] += imps;
                 o->clicks[base + k] += paid;
@@ -799,8 +839,8 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                         budget -= cost; cell_cost_sum += cost; ++paid;
                         o->cost[base + k] += cost;             /* obs cost = sum_list(costs): left-to-right */
                         int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w[3] < t_conv);
+                        int64_t rev = 0;
                         if (conv) {
-                            int64_t rev;
                             if (use_tape) rev = tape->rev_cents[tape->cur_rev++];
                             else {
                                 uint32_t w2[4];
@@ -811,6 +851,7 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                             o->revenue_cents[base + k] += rev;
                             cell_rev_c += rev;
                         }
+                        if (L) list_click(L, env, k, t, cost, conv ? (double)rev / 100.0 : -1.0);
                     } else broke = 1;
                 }
                 if (imps == 0) {
@@ -822,15 +863,18 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
                     if (clicked && budget >= 0.0) {
                         ++paid;
                         int conv = use_tape ? tape->conv[tape->cur_conv++] : ((uint64_t)w[1] < t_conv);
+                        int64_t rev = 0;
                         if (conv) {
-                            int64_t rev = use_tape ? tape->rev_cents[tape->cur_rev++]
-                                                   : orc_revenue_cents_from_word(w[2], rev_mu, rev_sd);
+                            rev = use_tape ? tape->rev_cents[tape->cur_rev++]
+                                           : orc_revenue_cents_from_word(w[2], rev_mu, rev_sd);
                             ++convs;
                             o->revenue_cents[base + k] += rev;
                             cell_rev_c += rev;
                         }
+                        if (L) list_click(L, env, k, t, 0.0, conv ? (double)rev / 100.0 : -1.0);   /* the reference lists the zero cost */
                     }
                 }
+                if (L) combine_cell(L, base + k, o->impressions[base + k], imps, n, (double)cell_rev_c / 100.0 - cell_cost_sum);
                 o->impressions[base + k] += imps;
                 o->clicks[base + k] += paid;
                 o->conversions[base + k] += convs;
@@ -879,23 +923,31 @@ static void step_env(const orc_config *c, orc_state *s, int env, const float *bi
     }
 }
 
-/* bids [N][K], budget [N]; tape (nullable) serves env 0..N-1 in order (cursors carry over). */
-ORC_API int32_t orc_step(const orc_config *c, orc_state *s, const float *bids, const float *budget,
-                         orc_tape *tape, orc_out *o)
+/* bids [N][K], budget [N]; tape (nullable) serves env 0..N-1 in order (cursors carry over); lists (nullable): the step's
+ * combined outcomes click by click (serial over envs). */
+ORC_API int32_t orc_step_outcomes(const orc_config *c, orc_state *s, const float *bids, const float *budget,
+                                  orc_tape *tape, orc_out *o, orc_outcomes *lists)
 {
     if (!c || !s || !bids || !budget || !o) return -1;
     if (c->num_envs <= 0 || c->num_keywords <= 0) return -1;
     if (!g_log_ready) build_log_table();
     if (!g_norm_ready) build_norm_table();
-    if (tape || c->threads <= 1) {
+    if (lists) lists->count = 0;
+    if (tape || lists || c->threads <= 1) {
         for (int e = 0; e < c->num_envs; ++e)
-            step_env(c, s, e, bids, budget[e], tape, o);
+            step_env(c, s, e, bids, budget[e], tape, o, lists);
     } else {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(c->threads)
         for (int e = 0; e < c->num_envs; ++e)
-            step_env(c, s, e, bids, budget[e], NULL, o);
+            step_env(c, s, e, bids, budget[e], NULL, o, NULL);
     }
     return 0;
+}
+
+ORC_API int32_t orc_step(const orc_config *c, orc_state *s, const float *bids, const float *budget,
+                         orc_tape *tape, orc_out *o)
+{
+    return orc_step_outcomes(c, s, bids, budget, tape, o, NULL);
 }
 
 /* force the pending drift into the stored parameters (what keyword_params shows after a step) */

@@ -45,6 +45,11 @@ class Out(C.Structure):
                                           "terminated", "truncated")]
 
 
+class Outcomes(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("count", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "env", "keyword", "timestep", "cost", "revenue", "impression_share", "profit")]
+
+
 class State(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("params", "key", "tick", "day", "cum_cents", "cum", "drift_pending")]
 
@@ -107,6 +112,9 @@ def lib():
                                             C.c_void_p, C.c_void_p]
         L.orc_step.restype = C.c_int32
         L.orc_step.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Out)]
+        L.orc_step_outcomes.restype = C.c_int32
+        L.orc_step_outcomes.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Out),
+                                        C.POINTER(Outcomes)]
         L.orc_materialize_drift.restype = C.c_int32
         L.orc_materialize_drift.argtypes = [C.POINTER(Config), C.POINTER(State)]
         L.orc_sample_bids.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
@@ -176,6 +184,45 @@ class OracleEngine:
                             C.byref(self._out))
         assert rc == 0
         return {k: v.copy() for k, v in self.out.items()}
+
+    def step_outcomes(self, bids, budget, tape=None, capacity=1 << 16):
+        """step() plus the combined BiddingOutcomes the reference would hand to repr_outcomes_py: (out, outcomes) with outcomes =
+        dict(costs, revenues, revenues_per_cost: [N][K] lists in the reference's order; impression_share, profit: [N, K])"""
+        N, K = self.N, self.K
+        bids = np.ascontiguousarray(bids, dtype=np.float32).reshape(N, K)
+        budget = np.ascontiguousarray(np.broadcast_to(np.asarray(budget, dtype=np.float32), (N,)))
+        while True:
+            snapshot = [a.copy() for a in (self.params, self.key, self.tick, self.day, self.cum_cents, self.cum, self.drift_pending)]
+            cursors = tape.cursors() if tape is not None else None
+            env, kw, ts = (np.zeros(capacity, np.int32) for _ in range(3))
+            cost, rev = np.zeros(capacity, np.float64), np.zeros(capacity, np.float64)
+            share, profit = np.zeros((N, K), np.float64), np.zeros((N, K), np.float64)
+            lists = Outcomes(capacity, 0, env.ctypes.data, kw.ctypes.data, ts.ctypes.data, cost.ctypes.data, rev.ctypes.data,
+                             share.ctypes.data, profit.ctypes.data)
+            rc = lib().orc_step_outcomes(C.byref(self.cfg), C.byref(self.state), bids.ctypes.data, budget.ctypes.data,
+                                         C.byref(tape.struct) if tape is not None else None, C.byref(self._out), C.byref(lists))
+            assert rc == 0
+            if lists.count <= capacity:
+                break
+            capacity = int(lists.count)             # did not fit: put the state back and walk the step again
+            for a, b in zip((self.params, self.key, self.tick, self.day, self.cum_cents, self.cum, self.drift_pending), snapshot):
+                a[...] = b
+            if tape is not None:
+                for n, v in cursors.items():
+                    setattr(tape.struct, "cur_" + n, v)
+        m = int(lists.count)
+        costs = [[[] for _ in range(K)] for _ in range(N)]
+        revenues = [[[] for _ in range(K)] for _ in range(N)]
+        rpc = [[[] for _ in range(K)] for _ in range(N)]
+        for i in range(m):
+            e, k = int(env[i]), int(kw[i])
+            costs[e][k].append(float(cost[i]))
+            rpc[e][k].append(max(float(rev[i]), 0.0))
+            if rev[i] >= 0:
+                revenues[e][k].append(float(rev[i]))
+        out = {k: v.copy() for k, v in self.out.items()}
+        return out, dict(costs=costs, revenues=revenues, revenues_per_cost=rpc, impression_share=share, profit=profit,
+                         keyword=kw[:m].copy(), timestep=ts[:m].copy(), env=env[:m].copy(), cost=cost[:m].copy(), revenue=rev[:m].copy())
 
     def materialize_drift(self):
         lib().orc_materialize_drift(C.byref(self.cfg), C.byref(self.state))

@@ -73,3 +73,21 @@ def assert_step_equal(got, ref, implicit=True):
     assert np.array_equal(got["days_passed"], ref["day"])
     assert np.array_equal(got["terminated"], ref["terminated"])
     assert np.array_equal(got["truncated"], ref["truncated"])
+
+
+def assert_outcome_lists(got, ref, K, env=0):
+    """the combined BiddingOutcomes (bidding_simulation.py:10-38,124-147) as the reference recorded them in a fixture (`ref`:
+    costs / revenues / revenues_per_cost per keyword, impression_share, profit) against regenerated ones (`got`: the same keys,
+    lists indexed [env][keyword] or [keyword]): every list element for element and in order, impression_share the very same
+    float64 (the lossy volume re-derivation of combine_outcomes included), profit within 1e-9 (its revenue sum is
+    ndarray::sum in the reference's Rust, un-buildable here: the order of that one sum is not pinned)."""
+    def row(x):
+        return x[env] if len(x) != K or (K and isinstance(x[0], list) and x[0] and isinstance(x[0][0], list)) else x
+    for name in ("costs", "revenues", "revenues_per_cost"):
+        lists = row(got[name])
+        assert len(lists) == K
+        for k in range(K):
+            assert [float(v) for v in lists[k]] == ref[name][k], (name, k)
+    share = np.asarray(got["impression_share"], dtype=np.float64).reshape(-1, K)[env]
+    assert share.tolist() == ref["impression_share"]
+    np.testing.assert_allclose(np.asarray(got["profit"], dtype=np.float64).reshape(-1, K)[env], ref["profit"], rtol=0, atol=1e-9)

@@ -125,6 +125,84 @@ def test_bidding_outcomes_cost_nothing_unread_and_expire_honestly(pkg):
     env.close()
 
 
+def test_bidding_outcomes_survive_a_keyword_params_read_under_drift(pkg):
+    """With drift on the last step's update_keywords() is pending on the device until somebody needs the parameters; reading
+    env.keyword_params (or str(info["keyword_params"])) writes it into the planes.  The step's per-click lists must still be the
+    step's own: the facade formats a still-unread info["bidding_outcomes"] before the parameters move, and an engine asked to
+    replay a step whose drift has been applied says so instead of regenerating clicks from moved parameters."""
+    import ast
+    env = pkg.BiddingSimulation(keyword_config=_cfg(60, 0.5), num_keywords=12, updater_mask=[True] * 12,
+                                updater_params=[["vol", 0.5], ["ctr", 0.5], ["cvr", 0.5]])
+    twin = pkg.BiddingSimulation(keyword_config=_cfg(60, 0.5), num_keywords=12, updater_mask=[True] * 12,
+                                 updater_params=[["vol", 0.5], ["ctr", 0.5], ["cvr", 0.5]])
+    env.reset(seed=11)
+    twin.reset(seed=11)
+    act = {"keyword_bids": np.full(12, 1.1), "budget": np.array([1.0e6])}
+    for _ in range(2):
+        obs, r, term, trunc, info = env.step(act)
+        obs2, *_, info2 = twin.step(act)
+    want = str(info2["bidding_outcomes"])                    # the twin reads its outcomes first: the step's own lists
+    p_before = [list(p) for p in env._params_host]
+    params = env.keyword_params                              # applies the pending drift on the device
+    assert any(p[3] != q[3] for p, q in zip(params, p_before))                       # the parameters really moved
+    text = str(info["bidding_outcomes"])
+    assert text == want
+    rows = ast.literal_eval(text)
+    assert [len(r["costs"]) for r in rows] == list(obs["buyside_clicks"]) and "per_click" not in rows[0]
+    # the engine's own guard (no facade in between): the drift of the last step has been applied -> ADC_ESTATE
+    with pytest.raises(AssertionError, match="already been applied"):
+        env._engine.outcomes_replay(0, np.full(12, 1.1, np.float32), 1.0e6)
+    # a dropped info costs nothing and the text falls back honestly when nobody kept the step's own
+    obs, r, term, trunc, info = env.step(act)
+    env._last_outcomes = None                                # (as if the caller had only kept a copy of the dict's other entries)
+    _ = env.keyword_params
+    late = ast.literal_eval(str(info["bidding_outcomes"]))
+    assert late[0]["per_click"] == "expired" and [r["buyside_clicks"] for r in late] == list(obs["buyside_clicks"])
+    env.close()
+    twin.close()
+
+
+def test_outcomes_replay_refuses_after_the_stream_or_the_parameters_were_rewritten(pkg):
+    """adc_engine_outcomes_replay recomputes the stream position and reads the parameters as they stand: after set_rng_state,
+    set_params / set_env_params, update_keywords or a generated keyword set it returns ADC_ESTATE, not plausible lists; days run
+    from a captured hipGraph count as steps."""
+    from adcraft_amd.engine import StepEngine
+    from tests import helpers as H
+    K = 32
+    planes = H.implicit_params(2, K, seed=4, mean_volume=30)
+    bids = np.full((2, K), 0.8, np.float32)
+    for change in ("rng", "params", "env_params", "general"):
+        e = StepEngine(2, K, seed=3, model=2 if change == "general" else 0)
+        e.set_all_params(planes)
+        e.reset()
+        e.step(bids, 1.0e6)
+        assert len(e.outcomes_replay(1, bids[1], 1.0e6)["keyword"]) > 0
+        if change == "rng":
+            e.set_rng_state(*e.get_rng_state())
+        elif change == "params":
+            e.set_all_params(planes)
+        elif change == "env_params":
+            e.set_env_params(0, planes[:, 0])
+        else:
+            e.set_general_model(20, 0.5, 1)
+        with pytest.raises(AssertionError):
+            e.outcomes_replay(1, bids[1], 1.0e6)
+        e.step(bids, 1.0e6)
+        assert len(e.outcomes_replay(1, bids[1], 1.0e6)["keyword"]) > 0          # the next step is replayable again
+        e.close()
+    e = StepEngine(2, K, seed=3)
+    e.set_all_params(planes)
+    e.reset()
+    e.sample_actions(0.3, 1.0, 1.0e6)
+    e.run_days("fixed", 5, graph=True)                       # the same actions every day; the captured pair replays the later days
+    e.synchronize()
+    got_bids, got_budget = e.get_actions()
+    rec = e.outcomes_replay(0, got_bids[0], float(got_budget[0]))
+    out = e.fetch()
+    assert np.bincount(rec["keyword"], minlength=K).tolist() == out["buyside_clicks"][0].tolist()
+    e.close()
+
+
 def test_reset_seed_reproduces_reference_keywords(pkg, golden):
     kat = golden("g2_keyword_params.json")["notebook_kat"]
     env = pkg.BiddingSimulation(keyword_config=_cfg(100, 0.3), num_keywords=30)

@@ -403,6 +403,84 @@ def test_g3_explicit_replay_on_gpu(amd, golden):
         e.close()
 
 
+def _implicit_planes(kp):
+    return np.array([[p["vol_mean"] for p in kp], [p["vol_std"] for p in kp], [p["loc"] for p in kp], [p["scale"] for p in kp],
+                     [p["bctr"] for p in kp], [p["sctr"] for p in kp], [p["rev_mean"] for p in kp], [p["rev_std"] for p in kp]],
+                    np.float32).reshape(8, 1, len(kp))
+
+
+def test_g3_outcome_lists_on_gpu_element_for_element(amd, golden):
+    """f4, second half: the per-click lists of info["bidding_outcomes"] against the reference's own BiddingOutcomes
+    (bidding_simulation.py:10-38,124-147, recorded by tools/gen_golden.py): step_replay on the reference's tape, then the
+    read-only walk of the same tape (adc_engine_outcomes_replay_tape) and the facade's combination of its click records -
+    costs, revenues, revenues_per_cost element for element and in order, impression_share the very same float64 (B-11's lossy
+    denominator included), per-keyword profit within 1e-9; and the formatted string (src/lib.rs:251-275) parsed back."""
+    import ast
+    from adcraft_amd.gymnasium_kw_env import BiddingSimulation, combined_outcomes
+    n_lossy = n_traces = 0
+    for model, name in ((0, "g3_implicit_replay.json"), (1, "g3_explicit_replay.json")):
+        for t in golden(name)["traces"]:
+            K, tp = t["K"], t["tape"]
+            e = amd.StepEngine(1, K, model=model, seed=1)
+            if model == 0:
+                e.set_all_params(_implicit_planes(t["keyword_params"]))       # (a tape replay reads none of them; the walk must not either)
+            e.reset()
+
+            def tape():
+                if model == 0:
+                    return amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"],
+                                          rev_cents=tp["rev"])
+                return amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"],
+                                      x_impressions=tp["impressions"], x_cost=tp["cost"])
+            bids = np.array(t["bids"], np.float32)
+            out = e.step_replay(bids, t["budget"], tape())
+            before = e.get_episode_state()
+            clicks = e.outcomes_replay(0, bids, t["budget"], tape=tape())
+            assert e.get_episode_state()[0].tolist() == before[0].tolist() and np.array_equal(e.get_episode_state()[1], before[1])   # read-only
+            obs = {k: out[k][0] for k in ("impressions", "buyside_clicks", "sellside_conversions", "cost", "revenue")}
+            rows = combined_outcomes(t["bids"], obs, clicks)
+            ref = t["out"]
+            got = {f: [r[f] for r in rows] for f in ("costs", "revenues", "revenues_per_cost", "impression_share", "profit")}
+            H.assert_outcome_lists(got, ref, K)
+            assert [r["buyside_clicks"] for r in rows] == ref["buyside_clicks"] == [len(c) for c in ref["costs"]]
+            # (c) the string the facade formats, parsed back
+            parsed = ast.literal_eval(BiddingSimulation._repr_outcomes(t["bids"], obs, clicks))
+            assert [list(r) for r in parsed][0] == ["bid", "impressions", "impression_share", "buyside_clicks", "costs", "sellside_conversions",
+                                                    "revenues", "revenues_per_cost", "profit"]
+            for k, r in enumerate(parsed):
+                assert r["bid"] == t["bids"][k] and r["impressions"] == ref["impressions"][k] and r["impression_share"] == ref["impression_share"][k]
+                assert r["costs"] == ref["costs"][k] and r["revenues"] == ref["revenues"][k] and r["revenues_per_cost"] == ref["revenues_per_cost"][k]
+                assert r["sellside_conversions"] == ref["sellside_conversions"][k] and abs(r["profit"] - ref["profit"][k]) < 1e-9
+            n_lossy += sum(1 for k in range(K) if t["volumes"][k] > 0 and ref["impressions"][k] > 0
+                           and ref["impression_share"][k] != ref["impressions"][k] / t["volumes"][k])
+            n_traces += 1
+            e.close()
+    assert n_traces >= 19 and n_lossy > 10
+
+
+def test_g8_outcome_lists_on_gpu_every_step(amd, golden):
+    """the same through whole step() episodes (what gymnasium_kw_env.py:249 hands to repr_outcomes_py), the tape cut per step"""
+    from adcraft_amd.gymnasium_kw_env import combined_outcomes
+    for ep in golden("g8_env_episodes.json")["episodes"]:
+        K, tp = ep["K"], ep["tape"]
+        e = amd.StepEngine(1, K, seed=1, max_days=ep["max_days"], loss_threshold=ep["loss_threshold"])
+        e.reset()
+        for st in ep["steps"]:
+            sl = st["tape_slices"]
+
+            def tape():
+                return amd.ReplayTape(1, np.array(st["volumes"]).reshape(1, K), bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"],
+                                      rev_cents=tp["rev"], offsets={k: [sl[k][0]] for k in ("bid", "click", "conv", "rev")})
+            bids = np.array(st["bids"], np.float32)
+            out = e.step_replay(bids, st["budget"], tape())
+            clicks = e.outcomes_replay(0, bids, st["budget"], tape=tape())
+            obs = {k: out[k][0] for k in ("impressions", "buyside_clicks", "sellside_conversions", "cost", "revenue")}
+            rows = combined_outcomes(st["bids"], obs, clicks)
+            H.assert_outcome_lists({f: [r[f] for r in rows] for f in ("costs", "revenues", "revenues_per_cost", "impression_share", "profit")},
+                                   st["outcomes"], K)
+        e.close()
+
+
 def test_g12_general_implicit_replay_on_gpu(amd, golden):
     """G12: the reference's default ImplicitKeyword (Binomial bidders per call, raw Laplace bids, literal top-(w+n) clearing)
     replayed through k_step_exact<IMPLICIT_GENERAL, TAPE>: integers exact, float64 cost sums bit-identical, cursors at the ends"""

@@ -123,6 +123,60 @@ def test_g3_explicit_replay(golden):
     assert any(c > i for t in g["traces"] for c, i in zip(t["out"]["buyside_clicks"], t["out"]["impressions"]))
 
 
+# ---------------------------------------------------------------- the per-click lists of info["bidding_outcomes"]
+def test_g3_outcome_lists_element_for_element(golden):
+    """f4: the combined BiddingOutcomes the reference builds (costs, revenues, revenues_per_cost per click in its order;
+    impression_share with combine_outcomes' lossy denominator; profit added up sub-timestep by sub-timestep -
+    bidding_simulation.py:10-38,97-147) replayed by the oracle from the reference's tapes: every list element for element"""
+    from tests import helpers as H
+    n_clicks = n_lossy = 0
+    for t in golden("g3_implicit_replay.json")["traces"]:
+        K = t["K"]
+        eng = orc.OracleEngine(1, K, model=orc.IMPLICIT)
+        _load_implicit(eng, t["keyword_params"])
+        tape = orc.TapeSource(bid_cents=t["tape"]["bid"], click=t["tape"]["click"], conv=t["tape"]["conv"], rev_cents=t["tape"]["rev"])
+        tape.set_volumes(np.array(t["volumes"]).reshape(1, K))
+        o, lists = eng.step_outcomes(np.array(t["bids"], dtype=np.float32), t["budget"], tape, capacity=64)   # (64: the regrow path too)
+        H.assert_outcome_lists(lists, t["out"], K)
+        assert [len(c) for c in lists["costs"][0]] == t["out"]["buyside_clicks"] == o["clicks"][0].tolist()
+        n_clicks += sum(t["out"]["buyside_clicks"])
+        # B-11: a sub-timestep without impressions drops out of the denominator - the share is NOT impressions / volume then
+        n_lossy += sum(1 for k in range(K) if t["volumes"][k] > 0 and t["out"]["impressions"][k] > 0
+                       and t["out"]["impression_share"][k] != t["out"]["impressions"][k] / t["volumes"][k])
+    assert n_clicks > 1000 and n_lossy > 10
+    n_phantom = 0
+    for t in golden("g3_explicit_replay.json")["traces"]:
+        K = t["K"]
+        eng = orc.OracleEngine(1, K, model=orc.EXPLICIT)
+        tape = orc.TapeSource(click=t["tape"]["click"], conv=t["tape"]["conv"], rev_cents=t["tape"]["rev"],
+                              x_impressions=t["tape"]["impressions"], x_cost=t["tape"]["cost"])
+        tape.set_volumes(np.array(t["volumes"]).reshape(1, K))
+        o, lists = eng.step_outcomes(np.array(t["bids"], dtype=np.float32), t["budget"], tape)
+        H.assert_outcome_lists(lists, t["out"], K)
+        n_phantom += sum(c.count(0.0) for c in t["out"]["costs"])
+    assert n_phantom > 0                      # the zero-cost phantom click (B-1) is listed, as the reference lists it
+
+
+def test_g8_outcome_lists_every_step(golden):
+    """the same for whole step() episodes: what BiddingSimulation.step hands to rust.repr_outcomes_py (gymnasium_kw_env.py:249)"""
+    from tests import helpers as H
+    for ep in golden("g8_env_episodes.json")["episodes"]:
+        K = ep["K"]
+        eng = orc.OracleEngine(1, K, model=orc.IMPLICIT, max_days=ep["max_days"], loss_threshold=ep["loss_threshold"])
+        tp = ep["tape"]
+        tape = orc.TapeSource(bid_cents=tp["bid"], click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"])
+        params = ep["params0"]
+        for st in ep["steps"]:
+            eng.params[:8, 0] = np.array([[p[0][0] for p in params], [p[0][1] for p in params], [p[1] for p in params],
+                                          [np.float32(1.0 / p[2]) for p in params], [p[3] for p in params], [p[4] for p in params],
+                                          [p[5] for p in params], [p[6] for p in params]], np.float32)
+            tape.set_volumes(np.array(st["volumes"]).reshape(1, K))
+            o, lists = eng.step_outcomes(np.array(st["bids"], dtype=np.float32), st["budget"], tape)
+            H.assert_outcome_lists(lists, st["outcomes"], K)
+            assert o["impressions"][0].tolist() == st["obs"]["impressions"]
+            params = st["params_after"]
+
+
 # ---------------------------------------------------------------- G12: the reference's default ImplicitKeyword
 def test_g12_general_implicit_replay(golden):
     """the non-env ImplicitKeyword (B ~ Binomial bidders per call, raw Laplace bids, literal top-(w+n) second-price clearing:

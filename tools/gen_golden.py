@@ -141,6 +141,14 @@ def L(a):
     return np.asarray(a).tolist()
 
 
+def outcome_lists(outcomes):
+    """the per-click lists of the combined BiddingOutcomes (bidding_simulation.py:10-38,124-147), in the reference's order:
+    what src/lib.rs:251-275 prints as 'costs' / 'revenues' / 'revenues_per_cost' of info["bidding_outcomes"]"""
+    return dict(costs=[[float(x) for x in o["costs"]] for o in outcomes],
+                revenues=[[float(x) for x in o["revenues"]] for o in outcomes],
+                revenues_per_cost=[[float(x) for x in o["revenues_per_cost"]] for o in outcomes])
+
+
 def cents(a):
     """2-dp dollars -> integer cents (exact: the reference rounded them to 2 dp)."""
     a = np.asarray(a, dtype=np.float64)
@@ -357,13 +365,16 @@ def gen_g3(u, b, c):
                      revenue=[float(np.sum(np.asarray(o["revenues"], dtype=np.float64))) if len(o["revenues"]) else 0.0
                               for o in outcomes],
                      profit=[float(o["profit"]) for o in outcomes],
-                     impression_share=[float(o["impression_share"]) for o in outcomes])))
+                     impression_share=[float(o["impression_share"]) for o in outcomes],
+                     **outcome_lists(outcomes))))
     dump("g3_implicit_replay.json", dict(
         source="adcraft/bidding_simulation.py:170-234 (simulate_epoch_of_bidding_on_campaign) over "
                "ImplicitKeyword objects from gymnasium_kw_utils.py:169-195, executed unmodified; "
                "tapes are the variates the reference drew, in call order (t-major, kw-minor): "
                "bid = competitor bids in cents (n per visited cell), click = booleans (one per won auction), "
-               "conv = booleans (one per paid click), rev = revenues in cents (one per conversion)",
+               "conv = booleans (one per paid click), rev = revenues in cents (one per conversion); "
+               "out.costs / revenues / revenues_per_cost = the combined outcomes' per-click lists per keyword in the reference's order, "
+               "out.impression_share / profit as combine_outcomes leaves them (bidding_simulation.py:124-147)",
         traces=traces))
 
 
@@ -476,14 +487,17 @@ def gen_g3_explicit(u, b, c, rust):
                      sellside_conversions=[int(o["sellside_conversions"]) for o in outcomes],
                      cost=[float(rust_sum_list(o["costs"])) for o in outcomes],
                      revenue=[float(rust_sum_list(o["revenues"])) for o in outcomes],
-                     profit=[float(o["profit"]) for o in outcomes])))
+                     profit=[float(o["profit"]) for o in outcomes],
+                     impression_share=[float(o["impression_share"]) for o in outcomes],
+                     **outcome_lists(outcomes))))
     dump("g3_explicit_replay.json", dict(
         source="adcraft/bidding_simulation.py:170-234 over ExplicitKeyword objects "
                "(adcraft/synthetic_kw_classes.py:457-575) built by gymnasium_kw_utils.py:67-96, executed unmodified; "
                "the three Rust samplers on this path are replaced by recorded injected samplers: "
                "tape.impressions/p = Binomial result and its p per visited cell, tape.cost = per-impression costs "
                "(the phantom [0] of synthetic_kw_classes.py:514-515 is produced by the reference itself and is NOT "
-               "on the tape), click/conv booleans and revenues in cents as in g3_implicit_replay",
+               "on the tape), click/conv booleans and revenues in cents as in g3_implicit_replay; out.costs / revenues / "
+               "revenues_per_cost / impression_share: the combined outcomes' per-click lists, as in g3_implicit_replay",
         traces=traces))
 
 
@@ -680,6 +694,11 @@ def gen_g8(env_mod, eq, c, rust):
             calls.append(out.copy())
             return out
         c.coinflips = rec_coin
+        # step() hands its combined outcomes to rust.repr_outcomes_py (gymnasium_kw_env.py:249): keep what it was given
+        seen = []
+        rust.repr_outcomes_py = lambda outcomes: (seen.append(dict(
+            impression_share=[float(o["impression_share"]) for o in outcomes], profit=[float(o["profit"]) for o in outcomes],
+            **outcome_lists(outcomes))), "")[1]
         steps = []
         try:
             for t in range(max_days):
@@ -696,11 +715,12 @@ def gen_g8(env_mod, eq, c, rust):
                     bids=L(bids), budget=budget, volumes=vol_log[nvol0:nvol0 + K],
                     tape_slices={k: [ntape0[k], len(tape[k])] for k in tape},
                     obs={k: L(v) for k, v in obs.items()}, reward=float(rew), terminated=bool(term),
-                    truncated=bool(trunc), params_after=params_to_json(env.keyword_params)))
+                    truncated=bool(trunc), params_after=params_to_json(env.keyword_params), outcomes=seen[-1]))
                 if term or trunc:
                     break
         finally:
             c.coinflips = orig_coin
+            rust.repr_outcomes_py = lambda outcomes: ""
         ok = True
         for st_ in steps:
             sl = st_["tape_slices"]
@@ -712,7 +732,8 @@ def gen_g8(env_mod, eq, c, rust):
         source="adcraft/gymnasium_kw_env.py:160-269 (BiddingSimulation.step) executed unmodified over recorded "
                "samplers; obs/reward/terminated/truncated are the reference's; params_after shows the drift of "
                "gymnasium_kw_env.py:114-158 (its uniforms are NOT on the tape: the engine's drift stream is its own; "
-               "drift arithmetic is pinned by g4)",
+               "drift arithmetic is pinned by g4); steps[].outcomes = the combined BiddingOutcomes step() passed to "
+               "rust.repr_outcomes_py (:249): per-click lists per keyword, impression_share, profit",
         episodes=eps))
 
 
