@@ -127,6 +127,9 @@ def lib():
         "adc_engine_profile_sample_every": ([vp, C.c_int32], C.c_int),
         "adc_engine_profile_read": ([vp, vp, C.POINTER(i64)], C.c_int),
         "adc_engine_profile_records": ([vp, C.POINTER(i64)], C.c_int),
+        "adc_engine_region_begin": ([vp], C.c_int),
+        "adc_engine_region_end": ([vp, C.POINTER(f64)], C.c_int),
+        "adc_engine_comm_stats": ([vp, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.c_int], C.c_int),
         "adc_engine_step_kernel_name": ([vp], C.c_char_p),
         "adc_engine_metrics_enable": ([vp, C.c_int], C.c_int),
         "adc_engine_metrics_reset": ([vp], C.c_int),

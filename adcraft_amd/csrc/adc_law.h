@@ -555,7 +555,14 @@ ADC_HD float fast_rcp(float x)
 }
 ADC_HD float min_num(float a, float b) { return __builtin_fminf(a, b); }       // the non-NaN operand if one is NaN
 ADC_HD float max_num(float a, float b) { return __builtin_fmaxf(a, b); }
-ADC_HD uint32_t sat_sub(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }      // v_sub_u32 ... clamp
+ADC_HD uint32_t sat_sub(uint32_t a, uint32_t b)                                                      // v_sub_u32 ... clamp
+{
+#if defined(__clang__)
+    return __builtin_elementwise_sub_sat(a, b);
+#else
+    return a > b ? a - b : 0u;          // (a host build by gcc: oracle/build.py build_shims_host)
+#endif
+}
 // float -> uint32: truncation, saturating at both ends, NaN -> 0 (v_cvt_u32_f32 does exactly this; spelled out for the host)
 ADC_HD uint32_t to_word(float x)
 {

@@ -467,6 +467,21 @@ class StepEngine:
         check(self._lib.adc_engine_comm_info(self._h, C.byref(r), C.byref(w)))
         return r.value, w.value
 
+    def comm_stats(self, reset=False):
+        """(calls, ms of this rank's own reduction kernels, ms of the ncclAllReduce) of the metric reductions so far"""
+        n, a, b = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+        check(self._lib.adc_engine_comm_stats(self._h, C.byref(n), C.byref(a), C.byref(b), 1 if reset else 0))
+        return n.value, a.value, b.value
+
+    def region_begin(self):
+        """one event on the engine's stream; region_end() -> GPU milliseconds since (one event pair for a whole timed region)"""
+        check(self._lib.adc_engine_region_begin(self._h))
+
+    def region_end(self):
+        ms = C.c_double(0.0)
+        check(self._lib.adc_engine_region_end(self._h, C.byref(ms)))
+        return ms.value
+
     def metrics_allreduce(self, ideal_k=None, ideal_pos_k=None):
         """the one collective of the path: (profit_cents[K], ideal[K], ideal_pos[K], scalars[8]) summed over steps, envs and
         the ranks of the engine's communicator (this rank alone without one)"""

@@ -86,7 +86,7 @@ def pmc_notes(cfg_name):
         return {}
 
 
-def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_baseline):
+def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_baseline, collective_alone=False):
     from adcraft_amd import _ffi, synthetic, distributed as D
     from adcraft_amd.engine import StepEngine
 
@@ -100,6 +100,15 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
     eng.sample_actions(0.30, 1.00, args.budget)  # actions resident in HBM before the timed region
     eng.metrics_enable(True)
     red = D.MetricReducer(eng, rank, world)      # world > 1: the engine's RCCL communicator (collective bring-up)
+    collective_error = None
+    if collective_alone and world == 1:
+        # one GPU: the same RCCL communicator with a single rank, so that the one collective of the path runs - and is timed -
+        # exactly where the N > 1 run has it (once per 60-step episode, inside the timed region)
+        try:
+            eng.comm_init(eng.comm_unique_id(), 0, 1)
+        except Exception as exc:                 # no usable librccl on this box: say so in the line, keep measuring the steps
+            collective_error = f"{type(exc).__name__}: {exc}"
+    with_collective = world > 1 or (collective_alone and collective_error is None)
     # stationary keywords: the ideal (max expected) profit per keyword is constant over the episode
     ideal_nk = eng.ideal_profit(2048)            # (with drift on this is the episode-start value)
     ideal_k, ideal_pos_k = ideal_nk.sum(axis=0), np.where(ideal_nk <= 0, 1.0, ideal_nk).sum(axis=0)
@@ -111,6 +120,15 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
     for _ in range(warmup):
         eng.step_device()
     red.metric_sums(ideal_k * warmup, ideal_pos_k * warmup)       # also brings the collective path up outside the timed region
+    barrier()
+    # a short timed region starts on clocks that are still ramping (a 20-step region measured 6 % slower than a 200-step one): more
+    # UNTIMED steps until the device has been busy for args.spin_seconds; the driver's --warmup steps above stay what they are
+    spin_steps, t_spin = 0, time.perf_counter()
+    while time.perf_counter() - t_spin < args.spin_seconds:
+        for _ in range(16):
+            eng.step_device()
+        eng.synchronize()
+        spin_steps += 16
     barrier()
     # kernel times: a separate, UNTIMED pass of the same length with HIP events around every step (four event records per step
     # keep a step's small tail kernels from overlapping the next step's launch: ~16 us of every step) ...
@@ -124,17 +142,26 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
     # ... and the timed region itself records no event at all
     eng.metrics_reset()
     records_before = eng.profile_records()
+    eng.comm_stats(reset=True)
     barrier()
+    collective_host_s = 0.0
+    eng.region_begin()                           # ONE event pair around the whole region: its GPU time, next to the host clock's
     t0 = time.perf_counter()
     for s in range(steps):
         eng.step_device()
-        if world > 1 and (s + 1) % MAX_DAYS == 0:
+        if with_collective and (s + 1) % MAX_DAYS == 0:
+            tc = time.perf_counter()
             red.metric_sums(ideal_k * (s + 1), ideal_pos_k * (s + 1))     # the single collective of the path, once per episode
+            collective_host_s += time.perf_counter() - tc
     barrier()
     elapsed = time.perf_counter() - t0
+    region_gpu_ms = eng.region_end()
     records_in_timed_region = eng.profile_records() - records_before
+    coll_calls, coll_ms_local, coll_ms_allreduce = eng.comm_stats(reset=True)
     profit_c, ideal, ideal_pos, sc = red.metric_sums(ideal_k * steps, ideal_pos_k * steps)
+    own_elapsed = elapsed
     elapsed = float(red.allreduce([elapsed], op="max")[0])          # the slowest rank's time
+    per_rank = red.allreduce(np.eye(world)[rank] * own_elapsed)     # every rank's own time, next to the slowest
     _, ranks_in_comm = eng.comm_info()
     n_gpus = ranks_in_comm if red.backend == "rccl" else world
 
@@ -152,6 +179,10 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                     f"no_vol_prob {no_vol_prob}, drift {drift}, budget {'non-binding' if args.budget >= 1e8 else args.budget}, "
                     f"{MAX_DAYS}-step episodes with auto-reset",
         "envs_per_gpu": N, "keywords": K,
+        "clock_spin_steps": spin_steps,
+        "timed_region": {"host_ms_per_step": own_elapsed / steps * 1e3, "gpu_ms_per_step": region_gpu_ms / steps,
+                         "method": "host clock between two barriers (the contract's figure) | one HIP event pair on the engine's stream "
+                                   "around the same region"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": notes.get("hbm_bytes_per_launch"),
@@ -175,6 +206,21 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                                 "valu_wave_instructions_per_launch": valu["wave_instructions_per_launch"],
                                 "valu_lane_instructions_per_auction": valu.get("valu_lane_instructions_per_auction"),
                                 "source": "instruction count: " + str(notes.get("source_note")) + "; kernel time: HIP events in this run"}
+    if world > 1:
+        res["ms_per_step_by_rank"] = [float(x) / steps * 1e3 for x in per_rank]
+    if with_collective or collective_error:
+        n_eff = max(coll_calls, 1)
+        res["collective"] = {
+            "what": "adc_engine_metrics_allreduce: this rank's column sums of the per-(env, keyword) profit accumulators (k_metric_columns, "
+                    f"k_metric_reduce, k_metric_vector), then ncclAllReduce(sum) of 3K + 8 = {3 * K + 8} doubles on the engine's stream",
+            "ranks": n_gpus, "calls_in_timed_region": int(coll_calls), "every_steps": MAX_DAYS,
+            "ms_per_call": {"own_reduction_kernels": coll_ms_local / n_eff, "allreduce": coll_ms_allreduce / n_eff,
+                            "host_call_incl_waiting_for_the_steps_before_it": collective_host_s / n_eff * 1e3},
+            "method": "three HIP events per call on the engine's stream (adc_engine_comm_stats); the host figure includes draining the "
+                      "steps already enqueued",
+        }
+        if collective_error:
+            res["collective"] = {"error": collective_error}
     akncp_ncp = D.episode_metrics(profit_c, ideal, ideal_pos, sc)
     res["episode_metric"] = {"AKNCP": akncp_ncp["AKNCP"], "NCP": akncp_ncp["NCP"], "profit_dollars": akncp_ncp["profit"],
                              "env_steps": akncp_ncp["env_steps"], "episodes": akncp_ncp["episodes"],
@@ -182,6 +228,8 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
     if with_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg_name, planes, K, args.cpu_seconds)
     red.close()
+    if collective_alone and world == 1 and collective_error is None:
+        eng.comm_destroy()
     eng.close()
     return res
 
@@ -252,11 +300,15 @@ def run_rank(args):
         return rehearse_rank(args, rank, world)
     main_cfg = args.config or ("cfg2" if world == 1 else "cfg4")
     also_cfgs = [] if args.no_also or args.config else (["cfg3", "cfg4", "cfg5"] if world == 1 else ["cfg5"])
-    main = run_config(main_cfg, args, rank, world, local_rank, args.steps, args.warmup, with_cpu_baseline=(world == 1 and rank == 0 and not args.no_cpu_baseline))
+    main = run_config(main_cfg, args, rank, world, local_rank, args.steps, args.warmup, with_cpu_baseline=(world == 1 and rank == 0 and not args.no_cpu_baseline),
+                      collective_alone=(args.config == "cfg4" and not args.no_collective_alone))
     also = {}
     for c in also_cfgs:
-        r = run_config(c, args, rank, world, local_rank, max(50, min(args.steps, 100)), max(10, min(args.warmup, 20)), with_cpu_baseline=False)
-        also[c] = {k: r[k] for k in ("value", "ms_per_step", "steps", "workload", "roofline", "episode_metric") if k in r}
+        # (cfg4 at N = 1: the N > 1 workload's per-GPU shard - with its collective, on a one-rank communicator, so that its cost is on record)
+        r = run_config(c, args, rank, world, local_rank, max(60 if c == "cfg4" else 50, min(args.steps, 100)), max(10, min(args.warmup, 20)),
+                       with_cpu_baseline=False, collective_alone=(c == "cfg4" and not args.no_collective_alone))
+        also[c] = {k: r[k] for k in ("value", "ms_per_step", "steps", "workload", "roofline", "episode_metric", "collective", "timed_region",
+                                     "clock_spin_steps", "ms_per_step_by_rank") if k in r}
         if "roofline_valu" in r:
             also[c]["roofline_valu"] = r["roofline_valu"]
     if rank == 0:
@@ -277,7 +329,7 @@ def run_rank(args):
             "env_steps_per_s": main["env_steps_per_s"],
             "roofline": main["roofline"],
         }
-        for k in ("roofline_valu", "episode_metric", "cpu_baseline"):
+        for k in ("timed_region", "clock_spin_steps", "ms_per_step_by_rank", "collective", "roofline_valu", "episode_metric", "cpu_baseline"):
             if k in main:
                 line[k] = main[k]
         if also:
@@ -311,7 +363,7 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1], text=True))
 
-    def end_job(reason):
+    def end_job(reason, relay_killed=False):
         for p in procs:
             if p.poll() is None:
                 p.kill()
@@ -322,7 +374,8 @@ def launch_ranks(args):
         for r, f in enumerate(errs):
             f.seek(0)
             tail = f.read()[-2000:]
-            if tail.strip() and codes[r] not in (0, -9):         # (-9: a rank this launcher ended itself)
+            # (-9: a rank this launcher ended itself - of interest only when the job hung: then what every rank last said is the evidence)
+            if tail.strip() and (relay_killed or codes[r] not in (0, -9)):
                 sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{tail}\n")
         for leftover in glob.glob(os.path.join(tempfile.gettempdir(), f"adcraft_comm_{port}_{job}.*")):
             shutil.rmtree(leftover, ignore_errors=True) if os.path.isdir(leftover) else os.remove(leftover)
@@ -338,7 +391,7 @@ def launch_ranks(args):
             if all(c == 0 for c in codes):
                 break
             if time.monotonic() > deadline:
-                end_job(f"no result after --launch-timeout {args.launch_timeout:.0f} s")
+                end_job(f"no result after --launch-timeout {args.launch_timeout:.0f} s", relay_killed=True)
             time.sleep(0.05)
         sys.stdout.write(procs[0].stdout.read())
         sys.stdout.flush()
@@ -363,6 +416,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary configs")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--spin-seconds", type=float, default=0.25, help="untimed steps for this long after the warm-up, so that a short timed "
+                    "region does not start on ramping clocks (0: none)")
+    ap.add_argument("--no-collective-alone", action="store_true", help="N = 1: do not bring up the one-rank RCCL communicator for cfg4")
     ap.add_argument("--rehearse", action="store_true", help="no GPU work: launch, id hand-over and reduction only (CPU test)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds the self-started ranks of --gpus N may take before the job is ended")

@@ -269,6 +269,11 @@ int adc_engine_profile_read(adc_engine *e, double *kernel_ms_total, int64_t *lau
 /* hipEventRecord calls the engine has issued since it was created (four per bracketed step): lets a benchmark show that
  * its timed region recorded none */
 int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
+/* GPU time of a whole region of the engine's stream from ONE event pair (nothing per step): `begin` records an event, `end`
+ * records another, waits for it and returns the milliseconds between the two - the figure a host-clock timing of K steps is
+ * checked against */
+int adc_engine_region_begin(adc_engine *e);
+int adc_engine_region_end(adc_engine *e, double *gpu_ms);
 /* name of the kernel the last step's first pass ran (the one kernel_ms_total[0] times): "k_step_implicit_fast<false>",
  * "k_step_implicit_fast<true>" (narrow tiles), "k_step_implicit_sparse", "k_step_general_fast", "k_step_explicit_fast", or
  * "k_step_exact" after a tape replay; "" before the first step.  A static string: do not free. */
@@ -292,6 +297,10 @@ int adc_engine_comm_info(adc_engine *e, int32_t *rank, int32_t *world_size);
  * steps, envs and ranks.  The ideal sums are the engine's own (adc_engine_ideal_step) when it accumulates them; otherwise
  * this rank's contribution may be passed as host vectors ideal_k / ideal_pos_k ([K] doubles each, NULL = zeros). */
 int adc_engine_metrics_allreduce(adc_engine *e, const double *ideal_k, const double *ideal_pos_k, double *out_3k8);
+/* what the metric reductions have cost on the device so far: calls of adc_engine_metrics_allreduce and the milliseconds (HIP events
+ * on the engine's stream, three records per call) of this rank's own reduction kernels and of the ncclAllReduce (0 without a
+ * communicator); reset != 0 zeroes the counters afterwards.  Any pointer may be NULL. */
+int adc_engine_comm_stats(adc_engine *e, int64_t *calls, double *ms_local_reduction, double *ms_allreduce, int reset);
 /* sum (op 0) or max (op 1) of `count` host doubles over the ranks, in place (a barrier is count = 1) */
 int adc_engine_comm_allreduce_f64(adc_engine *e, double *inout, int32_t count, int32_t op);
 
