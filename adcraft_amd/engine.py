@@ -500,7 +500,7 @@ class StepEngine:
 
     def run_days(self, policy, days, budget=100000.0, graph=None):
         """`days` days of the device-resident loop in one call; graph=True replays pairs of days from a captured
-        hipGraph (same results, measured no faster: tools/measure_small_loop.py)"""
+        hipGraph (same results, measured no faster: tools/experiments/measure_small_loop.py)"""
         if graph is not None:
             check(self._lib.adc_engine_day_graph_enable(self._h, 1 if graph else 0))
         check(self._lib.adc_engine_run_days(self._h, self.POLICIES[policy], int(days), float(budget)))
