@@ -75,8 +75,22 @@ def build_timing_variant():
     return out
 
 
+def build_variant(name, defines):
+    """lib/variants/<name>.so: the library with extra -D switches (ablations, experiments); select it with ADCRAFT_HIP_LIB=<path>.
+    Never loaded by default."""
+    out_dir = os.path.join(LIB_DIR, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, name + ".so")
+    srcs = [os.path.join(SRC_DIR, s) for s in SOURCES]
+    subprocess.check_call([HIPCC] + FLAGS + ["-Wno-unused-value", "-Wno-unused-variable"] + ["-D" + d for d in defines] + srcs + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
-    if "--timing" in sys.argv:
+    if "--variant" in sys.argv:          # python adcraft_amd/build.py --variant <name> <DEFINE[=value]> ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--timing" in sys.argv:
         print(build_timing_variant())
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -108,6 +108,106 @@ def test_sparse_kernel_forced(amd, monkeypatch, case):
         assert n > 0
 
 
+@pytest.mark.parametrize("kpl", ["2", "4"])
+@pytest.mark.parametrize("case", ["cfg3_law", "shapes", "many_items", "huge_keywords", "no_volume", "extreme_rates", "degenerate_laws",
+                                  "drift_autoreset", "binding_budget", "metrics"])
+def test_sparse_wave_kernel_forced(amd, monkeypatch, case, kpl):
+    """k_step_implicit_sparse_wave<KPL> (one wavefront per tile, KPL keywords per lane, records for live keywords only) forced on
+    every kind of input - also those the host's hint would never send to it: tiles whose live keywords / work items exceed the
+    records (resolved over several lane ranges), keyword-days too large for the 32-bit accumulators (the wavefront walk), ragged
+    keyword counts, drift, binding budgets.  Results may never depend on which kernel ran."""
+    monkeypatch.setenv("ADCRAFT_FAST_VARIANT", "2")
+    monkeypatch.setenv("ADCRAFT_FAST_TILE_KW", "256")
+    monkeypatch.setenv("ADCRAFT_SPARSE_WAVE", kpl)
+    monkeypatch.setenv("ADCRAFT_SPARSE_TILES_PER_WAVE", "3")
+    name = f"k_step_implicit_sparse_wave<{kpl}>"
+
+    def run(N, K, planes, **kw):
+        seen = []
+        orig = amd.StepEngine.step
+
+        def step(self, *a, **k):
+            out = orig(self, *a, **k)
+            seen.append(self.step_kernel_name())
+            return out
+        monkeypatch.setattr(amd.StepEngine, "step", step)
+        n = _run_vs_oracle(amd, N, K, planes, **kw)
+        monkeypatch.setattr(amd.StepEngine, "step", orig)
+        assert seen and all(x == name for x in seen), seen
+        return n
+
+    if case == "cfg3_law":
+        run(7, 1024, H.implicit_params(7, 1024, seed=31, mean_volume=16, cvr=0.1, no_vol_prob=0.5), steps=3, budget=1.0e9)
+    elif case == "shapes":
+        for N, K in ((5, 256), (3, 300), (4, 4), (2, 252), (3, 1028), (1, 8)):
+            run(N, K, H.implicit_params(N, K, seed=32 + K, mean_volume=12, cvr=0.5, no_vol_prob=0.3), steps=2, budget=1.0e9)
+    elif case == "many_items":              # dense keyword sets: far more live keywords and work items than a tile's records hold
+        run(3, 300, H.implicit_params(3, 300, seed=33, mean_volume=128), steps=2, budget=1.0e9)
+        run(2, 512, H.implicit_params(2, 512, seed=36, mean_volume=400), steps=2, budget=1.0e9)
+    elif case == "huge_keywords":           # beyond the 32-bit accumulators: volume, bid, revenue - the wavefront walk
+        planes = H.implicit_params(2, 40, seed=34, mean_volume=3000)
+        run(2, 40, planes, steps=2, budget=1.0e9)
+        planes = H.implicit_params(3, 260, seed=35, mean_volume=20, no_vol_prob=0.3)
+        planes[6, :, ::7] = 3.0e6           # revenue in millions of dollars
+        planes[7, :, ::7] = 1.0e5
+        planes[6, :, 3::11] = np.nan
+        run(3, 260, planes, steps=3, budget=1.0e9, bid_lo=0.3, bid_hi=1.0)
+        o = H.implicit_params(2, 64, seed=37, mean_volume=30)
+        o[2] *= 2.0e4                       # competitor bids of tens of thousands of dollars ...
+        o[3] *= 2.0e4
+        run(2, 64, o, steps=2, budget=1.0e12, bid_lo=5.0e3, bid_hi=3.0e4)          # ... and bids beyond 2^20 cents
+    elif case == "no_volume":
+        planes = H.implicit_params(3, 300, seed=35)
+        planes[0] = 0.0
+        planes[1] = 0.0
+        run(3, 300, planes, steps=2, budget=1.0e9)
+    elif case == "extreme_rates":
+        planes = H.implicit_params(4, 260, seed=36, mean_volume=20)
+        planes[4, 0] = 1.0
+        planes[4, 1] = 0.0
+        planes[4, 2] = np.float32(1e-9)
+        planes[4, 3] = np.float32(1.0 - 1e-7)
+        planes[5, 0] = 0.0
+        planes[5, 1] = 1.0
+        run(4, 260, planes, steps=3, budget=1.0e9, bid_lo=0.01, bid_hi=2.0)
+    elif case == "degenerate_laws":
+        planes = H.implicit_params(4, 260, seed=37, mean_volume=20)
+        planes[3, 0] = 0.0
+        planes[3, 1] *= 50.0
+        planes[3, 2] = np.float32(1e-6)
+        planes[2, 3] = -0.4
+        planes[2, 0, :9] = np.nan
+        planes[3, 0, 9:17] = np.inf
+        planes[4, 0, 17:25] = np.nan
+        run(4, 260, planes, steps=3, budget=1.0e9, bid_lo=0.01, bid_hi=1.5)
+    elif case == "drift_autoreset":
+        planes = H.implicit_params(5, 520, seed=38, mean_volume=16, cvr=0.1, no_vol_prob=0.5)
+        run(5, 520, planes, steps=7, budget=1e9, drift=True, check_params=True, max_days=3, loss_threshold=30.0, auto_reset=True)
+    elif case == "binding_budget":
+        planes = H.implicit_params(6, 300, seed=39, mean_volume=16, cvr=0.3, no_vol_prob=0.4)
+        assert run(6, 300, planes, steps=4, budget=6.0, bid_lo=0.5, bid_hi=1.2) > 0
+    else:
+        N, K = 4, 512
+        planes = H.implicit_params(N, K, seed=40, mean_volume=16, cvr=0.3, no_vol_prob=0.5)
+        planes[6, :, ::5] = 4.0e6           # (some keyword sums outgrow the 32-bit word: the spill)
+        e = amd.StepEngine(N, K, seed=9, drift_enabled=True)
+        e.set_all_params(planes)
+        e.reset()
+        e.metrics_enable(True)
+        e.metrics_reset()
+        o = H.mirror_oracle(e, planes, drift_on=True)
+        total = np.zeros((N, K), np.int64)
+        for budget in (1e9, 1e9, 3.0, 1e9, 1e9, 1e9):
+            bids = o.sample_bids(0.3, 1.0)
+            got, ref = e.step(bids, budget), o.step(bids, budget)
+            H.assert_step_equal(got, ref)
+            assert e.step_kernel_name() == name
+            total += ref["revenue_cents"] - ref["cost_cents"]
+        assert np.abs(total).max() > 2 ** 32
+        assert np.array_equal(np.rint(e.metrics_read_nk(ideal=False)[0] * 100).astype(np.int64), total)
+        e.close()
+
+
 def test_device_philox_is_the_batterys_philox_on_the_production_layout(amd):
     """the generator the stream battery tested on the CPU (oracle/stream_battery.c) is the one the GPU runs: 2^20 counters laid
     out as the kernels address them (index, stage, keyword, tick; env keys), word for word"""
@@ -886,6 +986,36 @@ def test_metric_accumulators(amd):
         tot += int(np.rint(out["reward"] * 100).sum())
     kp, sc = e.metrics_read()
     assert np.array_equal(kp, prof) and sc[0] == tot and sc[1] == 4 * N and sc[2] == N and sc[3] == 0
+    e.close()
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_metric_accumulators_beyond_32_bits(amd, monkeypatch, variant):
+    """the per-(env, keyword) profit sums are a 32-bit word + a 64-bit spill (common.inc metric_add): keywords whose revenue is
+    millions of dollars a conversion overflow the word within a step or two - the totals stay exact (oracle cents), in both
+    keyword-parallel kernels, through re-runs by the budget-exact kernels, and in every reader (columns, per-(env, keyword), median)"""
+    monkeypatch.setenv("ADCRAFT_FAST_VARIANT", variant)
+    N, K = 4, 300
+    planes = H.implicit_params(N, K, seed=35, mean_volume=40)
+    planes[6, :, ::3] = 4.0e6           # rev_mean in dollars: 4e8 cents per conversion
+    planes[7, :, ::3] = 1.0e6
+    planes[6, :, 1::3] = 9.0e6          # at the engine's money cap of 1e9 cents
+    e = amd.StepEngine(N, K, seed=9)
+    e.set_all_params(planes)
+    e.reset()
+    e.metrics_enable(True)
+    e.metrics_reset()
+    o = H.mirror_oracle(e, planes)
+    total = np.zeros((N, K), np.int64)
+    for budget in (1e9, 40.0, 1e9, 1e9, 40.0, 1e9):
+        bids = o.sample_bids(0.3, 1.0)
+        got, ref = e.step(bids, budget), o.step(bids, budget)
+        assert np.array_equal(got["sellside_conversions"], ref["conversions"]) and np.array_equal(got["reward"], ref["reward"])
+        total += ref["revenue_cents"] - ref["cost_cents"]
+    assert np.abs(total).max() > 2 ** 33
+    assert np.array_equal(np.rint(e.metrics_read_nk(ideal=False)[0] * 100).astype(np.int64), total)
+    kp, sc = e.metrics_read()
+    assert np.array_equal(kp, total.sum(axis=0)) and sc[0] == total.sum()
     e.close()
 
 
