@@ -609,11 +609,16 @@ def test_g12_general_implicit_replay_on_gpu(amd, golden):
         e.close()
 
 
-@pytest.mark.parametrize("budget,winners,pool", [(1e9, 1, (30, 0.6)), (3.0, 1, (30, 0.6)), (1e9, 2, (30, 0.6)), (1e9, 1, (3, 0.4)), (2.0, 2, (70, 0.5))])
-def test_general_implicit_matches_oracle(amd, budget, winners, pool):
+@pytest.mark.parametrize("small", ["0", "1"])
+@pytest.mark.parametrize("budget,winners,pool", [(1e9, 1, (30, 0.6)), (3.0, 1, (30, 0.6)), (1e9, 2, (30, 0.6)), (1e9, 1, (3, 0.4)), (2.0, 2, (70, 0.5)),
+                                                 (1e9, 1, (120, 0.97))])
+def test_general_implicit_matches_oracle(amd, monkeypatch, budget, winners, pool, small):
     """the engine's own stream for the default ImplicitKeyword model == the C oracle, bit for bit (incl. a binding budget,
-    two winning placements, pools smaller than w + n - zero padding - and larger than a wavefront), with drift"""
-    N, K = 3, 20
+    two winning placements, pools smaller than w + n - zero padding - and larger than a wavefront, a pool whose bidder count
+    goes by coins), with drift; through both keyword-parallel passes: a lane per keyword (k_step_general_fast) and eight lanes
+    per keyword for a handful of envs (k_step_general_small)"""
+    monkeypatch.setenv("ADCRAFT_GENERAL_SMALL", small)
+    N, K = 3, 45
     rng = np.random.default_rng(8)
     planes = np.stack([rng.integers(0, 90, (N, K)), rng.random((N, K)) * 6, rng.uniform(0.0, 0.3, (N, K)), rng.uniform(0.05, 0.15, (N, K)),
                        rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.3, 1.5, (N, K)),
@@ -629,6 +634,7 @@ def test_general_implicit_matches_oracle(amd, budget, winners, pool):
         bids = o.sample_bids(0.05, 0.5)
         got, ref = e.step(bids, b), o.step(bids, b)
         H.assert_step_equal(got, ref, implicit=False)
+        assert e.step_kernel_name() == ("k_step_general_small" if small == "1" else "k_step_general_fast")
     assert got["impressions"].sum() > 0
     o.materialize_drift()
     assert np.array_equal(e.get_all_params(), o.params)
