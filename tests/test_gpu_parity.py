@@ -615,7 +615,7 @@ def test_g12_general_implicit_replay_on_gpu(amd, golden):
 def test_general_implicit_matches_oracle(amd, monkeypatch, budget, winners, pool, small):
     """the engine's own stream for the default ImplicitKeyword model == the C oracle, bit for bit (incl. a binding budget,
     two winning placements, pools smaller than w + n - zero padding - and larger than a wavefront, a pool whose bidder count
-    goes by coins), with drift; through both keyword-parallel passes: a lane per keyword (k_step_general_fast) and eight lanes
+    goes by coins), with drift; through both keyword-parallel passes: a lane per keyword (k_step_general_fast) and a wavefront
     per keyword for a handful of envs (k_step_general_small)"""
     monkeypatch.setenv("ADCRAFT_GENERAL_SMALL", small)
     N, K = 3, 45
