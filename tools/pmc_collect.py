@@ -24,7 +24,7 @@ acc = collections.defaultdict(list)
 for name, counters in PASSES.items():
     d = os.path.join(out, f"{cfg}_{name}")
     cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "pmc", "--", "python3", "bench.py", "--config", cfg,
-           "--steps", "12", "--warmup", "2", "--no-cpu-baseline"]
+           "--steps", "12", "--warmup", "2", "--spin-seconds", "0", "--no-cpu-baseline"]
     with open(os.path.join(out, f"{cfg}_{name}.log"), "w") as log:
         subprocess.check_call(cmd, stdout=log, stderr=subprocess.STDOUT)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -40,14 +40,14 @@ rec = {
     "hbm_bytes_per_launch": 2.0 * m["FETCH_SIZE"] * 1024.0 + m["WRITE_SIZE"] * 1024.0,
     "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"],
     "algorithmic_bytes_per_launch": N * K * (68 if drift else 56) + 26 * N,
-    "algorithmic_bytes_incl_metric_mode": N * K * ((68 if drift else 56) + 16) + 26 * N,
+    "algorithmic_bytes_incl_metric_mode": N * K * ((68 if drift else 56) + 8) + 26 * N,
     "valu": {"wave_instructions_per_launch": m["SQ_INSTS_VALU"], "active_inst_valu_quad_cycles": m["SQ_ACTIVE_INST_VALU"],
              "wave_quad_cycles": m["SQ_WAVE_CYCLES"], "salu_instructions": m["SQ_INSTS_SALU"], "lds_instructions": m["SQ_INSTS_LDS"],
              "lds_active_quad_cycles": m["SQ_ACTIVE_INST_LDS"], "grbm_gui_active": m["GRBM_GUI_ACTIVE"], "waves": m["SQ_WAVES"],
              "auctions_per_launch_expected": auctions,
              "valu_lane_instructions_per_auction": m["SQ_INSTS_VALU"] * 64.0 / auctions},
-    "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 3); "
-                   "FETCH_SIZE doubled per the gfx950 correction; bench runs in metric mode (+16 B per keyword-step of accumulator traffic)",
+    "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 4); "
+                   "FETCH_SIZE doubled per the gfx950 correction; bench runs in metric mode (+8 B per keyword-step of accumulator traffic: a 32-bit word read and written)",
 }
 with open(os.path.join(out, f"pmc_{cfg}.json"), "w") as f:
     json.dump(rec, f, indent=1)

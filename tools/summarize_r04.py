@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""profiles/r04_final_rocprof_summary.md from the files tools/final_suite_r04.sh produced (copied to profiles/r04_final_* by
+tools/copy_final_r04.sh)"""
+import csv
+import json
+
+
+def top(path, n=6):
+    return list(csv.DictReader(open(path)))[:n]
+
+
+P = "profiles/r04_final_"
+runs = {c: json.load(open(f"{P}bench_{c}_under_rocprof.json")) for c in ("cfg2", "cfg3", "cfg4")}
+b = json.load(open(P + "bench.json"))
+ds = json.load(open(P + "bench_driver_shape.json"))
+pm = json.load(open("profiles/pmc_traffic.json"))
+L = ["# Round 4 - rocprofv3 evidence (1 x MI355X, builder-side gpurun box)\n",
+     "All from `tools/final_suite_r04.sh`.  Kernel traces: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-also --no-cpu-baseline` (the headline\n"
+     "workload alone), `... bench.py --config cfg3 --no-cpu-baseline`, `... --config cfg4` (the N > 1 workload's per-GPU shard, with its collective on a\n"
+     "one-rank communicator); PMC: three separate `--pmc` passes per config (`tools/pmc_collect.py`: FETCH_SIZE, WRITE_SIZE, SQ counters), kernel-trace\n"
+     "options only.\n"]
+for name, c in (("cfg2 (4096 x 256, dense; the bench line's workload)", "cfg2"), ("cfg3 (16384 x 1024, sparse)", "cfg3"),
+                ("cfg4 (8192 x 1024: one GPU's shard of 65536 x 1024)", "cfg4")):
+    bj = runs[c]
+    L.append(f"\n## {name}\n\n| kernel | calls | average (us) | share of GPU time |\n|---|---|---|---|")
+    for r in top(f"{P}kernel_stats_{c}.csv"):
+        L.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} % |")
+    L.append(f"\n`bench.py` in the same process (HIP events on the engine's stream): {bj['roofline']['kernel']} {bj['roofline']['kernel_ms'] * 1e3:.1f} us per launch, "
+             f"{bj['ms_per_step'] * 1e3:.1f} us per step by the host clock, {bj['timed_region']['gpu_ms_per_step'] * 1e3:.1f} us by one event pair around the timed region; "
+             f"`roofline.frac` {bj['roofline']['frac']:.4f}.")
+    if "collective" in bj:
+        L.append(f"The collective: {json.dumps(bj['collective']['ms_per_call'])} ms per call, {bj['collective']['calls_in_timed_region']} call(s), {bj['collective']['ranks']} rank(s).")
+L.append("\n## PMC (per launch of the step kernel - `k_step_implicit_fast<false>` on cfg2/4/5, `k_step_implicit_sparse` on cfg3; mean over dispatches)\n\n"
+         "| config | HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) | algorithmic bytes incl. metric-mode accumulators | VALU wave-instructions | lane-instructions per auction | LDS instructions | waves |\n"
+         "|---|---|---|---|---|---|---|")
+for c in ("cfg2", "cfg3", "cfg4", "cfg5"):
+    v = pm[c]
+    L.append(f"| {c} | {v['hbm_bytes_per_launch'] / 1e6:.1f} MB | {v['algorithmic_bytes_incl_metric_mode'] / 1e6:.1f} MB | {v['valu']['wave_instructions_per_launch']:.3g} | "
+             f"{v['valu']['valu_lane_instructions_per_auction']:.1f} | {v['valu']['lds_instructions']:.3g} | {v['valu']['waves']:.0f} |")
+L.append("\nThe metric-mode accumulators are a 32-bit word per keyword since round 4 (+8 B per keyword-step; round 3: +16).  `roofline_valu.frac` in the bench\n"
+         "line prices the VALU instructions against one wave-instruction per SIMD per 2 cycles; the ablation builds of the sparse kernel\n"
+         "(`profiles/r04_sparse_wave_kernel.txt`) put a wave-instruction of these kernels at about 4 cycles of its SIMD.\n")
+L.append("## The driver's command in the same run\n")
+L.append(f"`python bench.py --steps 20 --warmup 5` (the shape the driver uses): value {ds['value']:.4g} keyword-steps/s, {ds['ms_per_step']:.4f} ms/step "
+         f"({ds['clock_spin_steps']} untimed clock-spin steps before it), kernel {ds['roofline']['kernel_ms'] * 1e3:.1f} us; also: "
+         + ", ".join(f"{k} {v['ms_per_step']:.3f} ms/step (HBM frac {v['roofline']['frac']:.3f})" for k, v in ds['also'].items()) + ".\n")
+L.append("`python bench.py` (defaults: 200 steps):\n")
+L.append(f"value {b['value']:.4g} keyword-steps/s, {b['ms_per_step']:.4f} ms/step; also: "
+         + ", ".join(f"{k} {v['ms_per_step']:.3f} ms/step (HBM frac {v['roofline']['frac']:.3f})" for k, v in b['also'].items())
+         + f"; host_step {b['host_step']['ms']} ms (uint16 counts {b['host_step']['ms_u16_counts']} ms).\n")
+L.append("Other files of the suite: `r04_final_binding_budget.txt`, `r04_final_binding_wide.txt`, `r04_final_binding_wide_float_models.txt`, `r04_final_bench_budget*.json`,\n"
+         "`r04_final_kernel_stats_cfg2_budget*.csv` (binding budgets), `r04_final_general_model.txt` (the default ImplicitKeyword), `r04_final_ideal_step.txt`,\n"
+         "`r04_final_ideal_profit.txt`, `r04_final_closed_loop.txt`, `r04_final_sparse_floor.txt`, `r04_final_sparse_wave_kernel.txt`, `r04_final_vector_env.txt`,\n"
+         "`r04_final_small_env.txt`, `r04_final_soak_parity.txt` (randomised GPU-vs-oracle steps: all three models, both sparse kernels forced onto every shape,\n"
+         "both GENERAL passes, the rest-of-day pair, the click lists - bit-exact).\n")
+open("profiles/r04_final_rocprof_summary.md", "w").write("\n".join(L))
+print("written")
