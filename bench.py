@@ -298,6 +298,10 @@ def run_rank(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.rehearse:
         return rehearse_rank(args, rank, world)
+    # stdout carries ONE JSON line: whatever a library prints there (librccl's version banner at communicator bring-up) goes to stderr
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     main_cfg = args.config or ("cfg2" if world == 1 else "cfg4")
     also_cfgs = [] if args.no_also or args.config else (["cfg3", "cfg4", "cfg5"] if world == 1 else ["cfg5"])
     main = run_config(main_cfg, args, rank, world, local_rank, args.steps, args.warmup, with_cpu_baseline=(world == 1 and rank == 0 and not args.no_cpu_baseline),
@@ -336,7 +340,7 @@ def run_rank(args):
             line["also"] = also
         if world == 1 and not args.no_also and not args.config:
             line["host_step"] = host_step(local_rank)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=line_out, flush=True)
 
 
 def free_port():

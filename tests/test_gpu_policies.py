@@ -229,6 +229,25 @@ def test_device_median_matches_numpy_for_odd_even_and_padded_keyword_counts(amd,
     e.close()
 
 
+def test_device_median_propagates_nan_like_numpy(amd):
+    """np.median of a ratio vector that holds a NaN is NaN (closed_loop.py's host path); k_akncp_ncp sorts the NaN as +inf and
+    must still report NaN for that env, so that per_keyword_sums=True and False agree.  Here: a keyword without any auction
+    (profit 0 over ideal 0) in env 1 only."""
+    from adcraft_amd.closed_loop import run_baseline_episode
+    N, K, steps = 3, 33, 3
+    planes = H.implicit_params(N, K, seed=77, mean_volume=6, cvr=0.6, no_vol_prob=0.0)
+    planes[0, 1, 5] = 0.0           # vol_mean
+    planes[1, 1, 5] = 0.0           # vol_std
+    e = amd.StepEngine(N, K, seed=31, max_days=steps)
+    e.set_all_params(planes)
+    e.reset()
+    r = run_baseline_episode(e, "oracle", steps=steps, budget=100000.0, n_samples=256)
+    assert np.isnan(r["AKNCP"][1]) and np.isfinite(r["AKNCP"][[0, 2]]).all()
+    a_dev, n_dev = e.metrics_akncp_ncp(steps)
+    assert np.array_equal(a_dev, r["AKNCP"], equal_nan=True) and np.allclose(n_dev, r["NCP"], rtol=1e-12, atol=0)
+    e.close()
+
+
 @pytest.mark.parametrize("model", [0, 1])
 def test_run_days_graph_replay_equals_single_steps(amd, model):
     """adc_engine_run_days, plain and replaying pairs of days from a captured hipGraph: same trajectory as one call per

@@ -5,14 +5,18 @@ import csv
 import json
 
 
+def last_json_line(path):
+    return json.loads([ln for ln in open(path) if ln.startswith("{")][-1])
+
+
 def top(path, n=6):
     return list(csv.DictReader(open(path)))[:n]
 
 
 P = "profiles/r04_final_"
-runs = {c: json.load(open(f"{P}bench_{c}_under_rocprof.json")) for c in ("cfg2", "cfg3", "cfg4")}
-b = json.load(open(P + "bench.json"))
-ds = json.load(open(P + "bench_driver_shape.json"))
+runs = {c: last_json_line(f"{P}bench_{c}_under_rocprof.json") for c in ("cfg2", "cfg3", "cfg4")}
+b = last_json_line(P + "bench.json")
+ds = last_json_line(P + "bench_driver_shape.json")
 pm = json.load(open("profiles/pmc_traffic.json"))
 L = ["# Round 4 - rocprofv3 evidence (1 x MI355X, builder-side gpurun box)\n",
      "All from `tools/final_suite_r04.sh`.  Kernel traces: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-also --no-cpu-baseline` (the headline\n"
