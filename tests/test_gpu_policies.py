@@ -230,21 +230,30 @@ def test_device_median_matches_numpy_for_odd_even_and_padded_keyword_counts(amd,
 
 
 def test_device_median_propagates_nan_like_numpy(amd):
-    """np.median of a ratio vector that holds a NaN is NaN (closed_loop.py's host path); k_akncp_ncp sorts the NaN as +inf and
-    must still report NaN for that env, so that per_keyword_sums=True and False agree.  Here: a keyword without any auction
-    (profit 0 over ideal 0) in env 1 only."""
-    from adcraft_amd.closed_loop import run_baseline_episode
+    """np.median of a ratio vector that holds a NaN is NaN (closed_loop.py's host path); k_akncp_ncp sorts a NaN as +inf and must
+    still report NaN for that env, so that the device-side reduction and the host's agree.  Here: days stepped without any ideal
+    profit accumulated (denominators 0) and a keyword without auctions in env 1 (profit 0): 0 / 0 among +-inf."""
     N, K, steps = 3, 33, 3
     planes = H.implicit_params(N, K, seed=77, mean_volume=6, cvr=0.6, no_vol_prob=0.0)
     planes[0, 1, 5] = 0.0           # vol_mean
     planes[1, 1, 5] = 0.0           # vol_std
-    e = amd.StepEngine(N, K, seed=31, max_days=steps)
+    e = amd.StepEngine(N, K, seed=31, max_days=1000)
     e.set_all_params(planes)
     e.reset()
-    r = run_baseline_episode(e, "oracle", steps=steps, budget=100000.0, n_samples=256)
-    assert np.isnan(r["AKNCP"][1]) and np.isfinite(r["AKNCP"][[0, 2]]).all()
-    a_dev, n_dev = e.metrics_akncp_ncp(steps)
-    assert np.array_equal(a_dev, r["AKNCP"], equal_nan=True) and np.allclose(n_dev, r["NCP"], rtol=1e-12, atol=0)
+    e.bid_curves_build(256)
+    e.metrics_enable(True)
+    e.ideal_step()
+    e.metrics_reset()               # the sums are zero again
+    e.sample_actions(0.3, 1.0, 100000.0)
+    for _ in range(steps):
+        e.step_device()
+    profit, ideal, ideal_pos = e.metrics_read_nk()
+    assert profit[1, 5] == 0.0 and not ideal_pos.any()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        host = np.median((profit / steps) / (ideal_pos / steps), axis=1)
+    assert np.isnan(host[1])
+    a_dev, _ = e.metrics_akncp_ncp(steps)
+    assert np.array_equal(a_dev, host, equal_nan=True)
     e.close()
 
 
