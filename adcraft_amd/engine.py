@@ -345,6 +345,12 @@ class StepEngine:
         check(self._lib.adc_debug_walk_stats(self._h, out.ctypes.data, 1 if reset else 0))
         return out
 
+    def direct_days(self, reset=False):
+        """env-days handed to k_step_rest_of_day without the row kernel, on this device (adc_debug_direct_days)"""
+        out = np.zeros(1, dtype=np.int64)
+        check(self._lib.adc_debug_direct_days(self._h, out.ctypes.data, 1 if reset else 0))
+        return int(out[0])
+
     def step_kernel_name(self):
         """the first-pass kernel of the last step (the one profile_read()'s first duration times)"""
         return self._lib.adc_engine_step_kernel_name(self._h).decode()

@@ -352,6 +352,35 @@ def test_rest_of_day_pair_matches_oracle(amd, monkeypatch, case, budget):
         assert n > 0
 
 
+@pytest.mark.parametrize("drift", [False, True])
+def test_rest_of_day_at_once_matches_oracle(amd, monkeypatch, drift):
+    """A budget that runs out within the first cells of the day: from the next day on k_tail_or_flag parks the env for
+    k_step_rest_of_day at once (hint 6) - no fast pass, no row kernel; the pass draws the volumes and applies the drift itself.
+    Bit-exact against the oracle through budgets that stay small, grow (back through the row kernel), stop binding, are zero
+    (the first cell is still visited, :230-233) and exhaust to the cent (campaign stop); the counter shows the path ran."""
+    monkeypatch.setenv("ADCRAFT_CLICK_WALK", "0")
+    monkeypatch.setenv("ADCRAFT_REST_SPLIT", "1")            # (the default splits from 1024 envs on)
+    for N, K, seed, vol in ((6, 256, 61, 40), (3, 77, 62, 60)):
+        planes = H.implicit_params(N, K, seed=seed, mean_volume=vol)
+        e = amd.StepEngine(N, K, seed=11, drift_enabled=drift, max_days=1000, loss_threshold=1e9)
+        e.set_all_params(planes)
+        e.reset()
+        e.direct_days(reset=True)
+        o = H.mirror_oracle(e, planes, drift_on=drift, max_days=1000, loss_threshold=1e9)
+        budgets = [3.0, 3.0, 3.0, 2.5, 20.0, 20.0, 400.0, 3.0, 3.0, 1e9, 3.0, 3.0, 3.0, 0.0, 0.05, 0.05, 0.05, 3.0]
+        seen = []
+        for budget in budgets:
+            bids = o.sample_bids(0.4, 1.2)
+            H.assert_step_equal(e.step(bids, budget), o.step(bids, budget), implicit=True)
+            seen.append(e.direct_days())
+        assert seen[1] == 0 and seen[2] > 0          # the first binding day tells the host, the second earns the hint, the third uses it
+        assert seen[-1] > seen[10] > seen[3]         # ... and again after the larger budgets and the day that did not bind
+        if drift:
+            o.materialize_drift()
+            assert np.array_equal(e.get_all_params(), o.params)
+        e.close()
+
+
 def test_mixed_binding_and_not(amd):
     """some envs hit the budget, others do not, in the same launch"""
     N, K = 8, 64

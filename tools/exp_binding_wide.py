@@ -14,9 +14,10 @@ for N, K in ((2048, 1024), (4096, 512)):
         eng.set_all_params(planes)
         eng.reset()
         eng.sample_actions(0.30, 1.00, budget)
-        for _ in range(6):
-            eng.step_device()
-        eng.synchronize()
+        for _ in range(3):      # (between launches the host learns what the device found out)
+            for _ in range(3):
+                eng.step_device()
+            eng.synchronize()
         t0 = time.perf_counter()
         n = 30
         for _ in range(n):

@@ -21,9 +21,10 @@ eng.sample_actions(0.30, 1.00, budget)
 L = _ffi.lib()
 L.adc_debug_read.argtypes = [C.c_void_p, C.c_int]
 out = (C.c_ulonglong * 16)()
-for _ in range(5):
-    eng.step_device()
-eng.synchronize()
+for _ in range(4):          # (the host learns what the device found out - budgets bind, envs to park at once - between launches)
+    for _ in range(3):
+        eng.step_device()
+    eng.synchronize()
 L.adc_debug_read(out, 1)
 eng.profile_enable(True)
 eng.profile_read()
@@ -41,3 +42,4 @@ print(f"env-days/step {v[4] / steps:.0f}  rows/env-day {v[5] / max(v[4], 1):.2f}
 for i, n in enumerate(["passA", "resolve (incl. chain)", "  chain + its barrier", "passB"]):
     print(f"{n:24s} {v[i] * 10 / max(v[5], 1) / 1e3:8.2f} us/row   {v[i] * 10e-9 * 1e3 / steps:8.2f} block-ms/step")
 eng.walk_stats()      # (timing build: prints the phase sums of k_step_click_walk and k_step_rest_of_day to stderr)
+print("env-days parked at once (adc_debug_direct_days):", eng.direct_days())
