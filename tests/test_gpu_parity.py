@@ -346,7 +346,7 @@ def test_rest_of_day_pair_matches_oracle(amd, monkeypatch, case, budget):
     if case == "few_marks_then_table": monkeypatch.setenv("ADCRAFT_REST_MARKS", "3")
     if case == "table_only": monkeypatch.setenv("ADCRAFT_REST_MARKS", "0")
     monkeypatch.setenv("ADCRAFT_REST_SPLIT", "0" if case == "one_kernel" else "1")       # (the default splits from 1024 envs on)
-    for N, K, seed, vol in ((5, 256, 51, 60), (3, 77, 52, 60), (2, 40, 53, 2500)):     # (cells of 2-3 auctions; of a hundred)
+    for N, K, seed, vol in ((5, 256, 51, 60), (3, 77, 52, 60), (2, 40, 53, 2500), (2, 300, 54, 50), (2, 1024, 55, 40)):     # (cells of 2-3 auctions; of a hundred; several keywords per lane)
         planes = H.implicit_params(N, K, seed=seed, mean_volume=vol)
         n = _run_vs_oracle(amd, N, K, planes, steps=3, budget=budget, bid_lo=0.4, bid_hi=1.2)
         assert n > 0
