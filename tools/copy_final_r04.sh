@@ -10,6 +10,7 @@ cp $F/ideal_step.txt $P/r04_final_ideal_step.txt; cp $F/ideal_profit.txt $P/r04_
 cp $F/sparse_floor.txt $P/r04_final_sparse_floor.txt; cp $F/sparse_wave.txt $P/r04_final_sparse_wave_kernel.txt
 cp $F/vector_env.txt $P/r04_final_vector_env.txt; cp $F/small_env.txt $P/r04_final_small_env.txt
 cp $F/binding_wide_float.txt $P/r04_final_binding_wide_float_models.txt
+cp $F/kernel_stats_wide_binding.txt $P/r04_final_kernel_stats_wide_binding.txt
 for b in 1000 10; do cp $F/kernel_stats_budget$b.csv $P/r04_final_kernel_stats_cfg2_budget$b.csv; done
 (for f in $F/soak_*.txt; do echo "== $(basename $f .txt)"; tail -n 4 $f; done) > $P/r04_final_soak_parity.txt
 python3 - <<'PY'

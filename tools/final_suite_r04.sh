@@ -40,6 +40,8 @@ timeout -k 10 300 python3 tools/soak_parity.py 80 403 general > $OUT/soak_genera
 ADCRAFT_GENERAL_SMALL=0 timeout -k 10 300 python3 tools/soak_parity.py 60 408 general > $OUT/soak_general_lane_per_keyword.txt 2>&1 || exit 1
 ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 60 405 > $OUT/soak_implicit_rest_pair.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 60 409 lists > $OUT/soak_implicit_lists.txt 2>&1 || exit 1
+ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 60 410 small > $OUT/soak_implicit_at_once.txt 2>&1 || exit 1
+for shape in "2048 1024 4000" "2048 1024 40" "4096 512 4000" "4096 512 40"; do bash tools/kt_shape.sh $shape >> $OUT/kernel_stats_wide_binding.txt 2>&1 || exit 1; done
 for b in 1000 10; do ADCRAFT_CLICK_WALK=0 bash tools/kt_budget.sh $b > /dev/null 2>&1 || exit 1; cp gpurun_out/kt_b$b/kt_kernel_stats.csv $OUT/kernel_stats_budget$b.csv; done
 for f in $OUT/soak_*.txt; do echo "$f: $(tail -n1 $f)"; done
 echo done

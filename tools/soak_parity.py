@@ -17,7 +17,8 @@ budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 explicit = len(sys.argv) > 3 and sys.argv[3] == "explicit"      # the default-constructor (ExplicitKeyword) model
 general = len(sys.argv) > 3 and sys.argv[3] == "general"        # the default ImplicitKeyword (bidder pools, top-(w+n) clearing)
-lists = len(sys.argv) > 3 and sys.argv[3] == "lists"
+lists = len(sys.argv) > 3 and sys.argv[3] in ("lists", "small")
+small = len(sys.argv) > 3 and sys.argv[3] == "small"      # budgets that run out within the first cells of the day, day after day (hint 6: parked at once)
 t0 = time.time()
 cases = steps = reruns = 0
 last_report = t0
@@ -68,6 +69,8 @@ while time.time() - t0 < budget_s:
         budget = rng.choice([1e9, 500.0, 50.0, 5.0, 0.3, 0.0], size=N).astype(np.float32)
         if lists and day_cost is not None:
             frac = rng.choice([0.02, 0.2, 0.5, 0.8, 0.97, 3.0], size=N, p=[0.15, 0.25, 0.25, 0.2, 0.1, 0.05])
+            if small:
+                frac = rng.choice([0.0005, 0.002, 0.006, 0.02, 0.3, 3.0], size=N, p=[0.25, 0.3, 0.25, 0.1, 0.05, 0.05])
             budget = np.maximum(day_cost * frac, 0.01).astype(np.float32)
         elif lists:
             budget = np.full(N, 1e9, dtype=np.float32)
@@ -86,8 +89,10 @@ while time.time() - t0 < budget_s:
         assert np.array_equal(e.get_all_params(), o.params)
     if lists:
         walk = e.walk_stats().tolist()          # (the device's counters: cumulative over the process)
+        at_once = e.direct_days()
     e.close()
     cases += 1
 if lists:
+    print(f"env-days parked at once by k_tail_or_flag: {at_once}")
     print(f"k_step_click_walk: {walk[0]} env-days walked ({walk[2]} of them with a campaign stop), {walk[1]} lists overflowed, {walk[3]} other hand-overs")
 print(f"soak ok: {cases} engines, {steps} steps, {reruns} budget-bound env-steps, {time.time() - t0:.0f} s")
