@@ -1062,6 +1062,20 @@ def test_exact_rows_shapes_and_edge_budgets(amd, N, K, budget):
     _run_vs_oracle(amd, N, K, planes, steps=2, budget=budget, bid_lo=0.4, bid_hi=1.1)
 
 
+@pytest.mark.parametrize("wide", [0, 1, 2, 3])
+@pytest.mark.parametrize("K", [300, 512, 513, 1024, 1500])
+def test_row_kernel_with_wider_workgroups(amd, monkeypatch, K, wide):
+    """k_step_exact_rows with 512 or 1024 lanes per workgroup (ADCRAFT_ROWS_WIDE: 0 = 256 lanes taking several cells per lane and
+    row, 1 = a lane per keyword up to 1024, 2 = 512 lanes, 3 = 512 lanes beyond 512 keywords) - budgets that bind late, early,
+    stop the campaign, are zero; drift; the rest of the day by the pair of kernels and by the one"""
+    monkeypatch.setenv("ADCRAFT_ROWS_WIDE", str(wide))
+    for split, budget, drift in ((1, 300.0, False), (0, 25.0, True), (1, 0.6, True), (1, 0.0, False)):
+        monkeypatch.setenv("ADCRAFT_REST_SPLIT", str(split))
+        planes = H.implicit_params(3, K, seed=70 + K, mean_volume=30)
+        n = _run_vs_oracle(amd, 3, K, planes, steps=4, budget=budget, bid_lo=0.4, bid_hi=1.1, drift=drift, check_params=drift)
+        assert n > 0
+
+
 def test_exact_pass_sparse_and_large_cells(amd):
     planes = H.implicit_params(3, 200, seed=43, mean_volume=16, cvr=0.5, no_vol_prob=0.5)
     _run_vs_oracle(amd, 3, 200, planes, steps=3, budget=2.0)
