@@ -958,6 +958,53 @@ def test_full_size_cfg5_shard_properties_with_drift(amd):
     _full_size_properties(amd, "cfg5", steps=3)
 
 
+@pytest.mark.parametrize("shape,budget", [("cfg2", 1000.0), ("cfg2", 10.0), ((2048, 1024), 4000.0), ((2048, 1024), 40.0), ((4096, 512), 200.0)])
+def test_full_size_binding_budgets(amd, shape, budget):
+    """Every env's budget binding at BASELINE's full sizes (configs[1] and the K = 1024 / 512 shapes of the 8-GPU configs' shards),
+    six days in a row, so that what the device tells the host between launches takes effect - the rest-of-day pair, envs parked
+    at once: the domain's properties (nobody spends more than the budget; click <= impression, conversion <= click; the reward
+    is the checksum of the per-keyword checksums) and a 4-env slice of the big launch against the CPU oracle on the same envs,
+    bit for bit, every day."""
+    from adcraft_amd import synthetic
+    from oracle import capi as orc
+    if isinstance(shape, str):
+        N, K, mean_volume, cvr, no_vol_prob, _ = synthetic.CONFIGS[shape]
+    else:
+        (N, K), mean_volume, cvr, no_vol_prob = shape, 128, 0.8, 0.0
+    planes = H.implicit_params(N, K, seed=1741, mean_volume=mean_volume, cvr=cvr, no_vol_prob=no_vol_prob)
+    e = amd.StepEngine(N, K, seed=1741, drift_enabled=True, max_days=1000, loss_threshold=1e12)
+    e.set_all_params(planes)
+    e.reset()
+    e.direct_days(reset=True)
+    k0, t0 = e.get_rng_state()
+    sub = slice(N // 5, N // 5 + 4)
+    o = orc.OracleEngine(4, K, drift_on=True, max_days=1000, loss_threshold=1e12)
+    o.params[:] = planes[:, sub]
+    o.key[:] = k0[sub]
+    o.tick[:] = t0[sub]
+    budget_c = int(np.rint(np.float64(np.float32(budget)) * 100))
+    bound = 0
+    for s in range(6):
+        e.sample_actions(0.3, 1.0, budget)
+        e.step_device()
+        a = e.fetch()
+        spend = np.rint(a["cost"].astype(np.float64) * 100).sum(axis=1)
+        assert (spend <= budget_c).all()
+        bound += int((spend >= budget_c - 150).sum())                  # (within a click or two of the budget)
+        assert (a["buyside_clicks"] <= a["impressions"]).all() and (a["sellside_conversions"] <= a["buyside_clicks"]).all()
+        assert (a["cost"][a["buyside_clicks"] == 0] == 0).all() and (a["revenue"][a["sellside_conversions"] == 0] == 0).all()
+        cents = np.rint(a["revenue"].astype(np.float64) * 100) - np.rint(a["cost"].astype(np.float64) * 100)
+        assert np.array_equal(np.rint(a["reward"] * 100), cents.sum(axis=1))          # checksum of checksums
+        ref = o.step(o.sample_bids(0.3, 1.0), budget)
+        H.assert_step_equal({k: v[sub] for k, v in a.items()}, ref)
+    assert bound > 5 * N                                                # the budgets did bind
+    if shape == "cfg2" and budget == 10.0:
+        assert e.direct_days() > 2 * N                                  # ... and most days were parked at once
+    o.materialize_drift()
+    assert np.array_equal(e.get_all_params()[:, sub], o.params)
+    e.close()
+
+
 # ------------------------------------------------------------------ metrics on the device
 def test_bid_curves_estimator_matches_reference(amd, golden):
     """k_ideal_profit's estimator on the reference's own samples == get_implicit_kw_bid_cpc_impressions (G5)"""
