@@ -288,6 +288,45 @@ def test_run_days_graph_replay_equals_single_steps(amd, model):
         assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
 
 
+@pytest.mark.parametrize("budget", [2.0, 60.0])
+def test_run_days_graph_replay_with_the_rest_of_day_kernels(amd, monkeypatch, budget):
+    """The same with every budget binding and the pair of rest-of-day kernels forced (ADCRAFT_REST_SPLIT=1; the default
+    takes it from 1024 envs on): the graphs are captured before and after the device has told the host that budgets bind and
+    that envs are parked at once (budget 2), and must be re-captured when it has; memory those paths need is allocated between
+    captures, never inside one.  Same trajectory as one call per day."""
+    monkeypatch.setenv("ADCRAFT_REST_SPLIT", "1")
+    monkeypatch.setenv("ADCRAFT_CLICK_WALK", "0")
+    N, K = 6, 200
+    planes = H.implicit_params(N, K, seed=97, mean_volume=40, cvr=0.6)
+    outs = []
+    for graph in (True, False, None):
+        e = amd.StepEngine(N, K, seed=33, drift_enabled=True, drift=(0.05, 0.05, 0.05), max_days=1 << 20, loss_threshold=1e12)
+        e.set_all_params(planes)
+        e.reset()
+        e.direct_days(reset=True)
+        e.sample_actions(0.4, 1.2, budget)
+        e.metrics_enable(True)
+        for days in (5, 6, 7, 4, 9):
+            if graph is not None:
+                e.run_days("fixed", days, graph=graph)
+                e.synchronize()                       # (the host reads the device's flags between calls)
+            else:
+                for _ in range(days):
+                    e.step_device()
+                e.synchronize()
+        o = e.fetch()
+        outs.append((o, e.get_all_params(), e.metrics_read_nk(ideal=False)[0], e.get_rng_state(), e.direct_days()))
+        e.close()
+    for a in outs[:2]:
+        b = outs[2]
+        for k in a[0]:
+            assert np.array_equal(a[0][k], b[0][k]), k
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
+    if budget == 2.0:
+        assert outs[0][4] > 0 and outs[2][4] > 0      # envs were parked at once, under graph replay too
+
+
 def test_day_graph_is_recaptured_when_settings_change(amd):
     """The kernel nodes of a captured day hold the engine's settings by value.  Changing any of them between two
     run_days(graph=True) calls - metrics on/off, episode limits, drift, flat observations, the bid-curve grid (which
