@@ -46,7 +46,7 @@ class Tape(C.Structure):
 
 
 _lib = None
-ABI_VERSION, STREAM_REVISION = 4, 4           # include/adcraft_engine.h ADC_ABI_VERSION, ADC_STREAM_REVISION
+ABI_VERSION, STREAM_REVISION = 5, 4           # include/adcraft_engine.h ADC_ABI_VERSION, ADC_STREAM_REVISION
 
 
 def library_path():
@@ -98,6 +98,7 @@ def lib():
         "adc_engine_set_env_params": ([vp, C.c_int, vp], C.c_int),
         "adc_engine_reset": ([vp, vp, vp], C.c_int),
         "adc_engine_generate_keywords": ([vp, C.POINTER(Quantiles), f32, C.c_uint32, vp], C.c_int),
+        "adc_engine_generate_explicit_keywords": ([vp, C.c_uint32, vp], C.c_int),
         "adc_engine_set_limits": ([vp, i32, f64], C.c_int),
         "adc_engine_set_drift": ([vp, i32, f32, f32, f32], C.c_int),
         "adc_engine_get_rng_state": ([vp, vp, vp], C.c_int),
@@ -152,6 +153,7 @@ def lib():
         "adc_auction_word_intervals": ([f32, f32, f32, f32, vp], C.c_int),
         "adc_auction_word_brackets": ([f32, f32, f32, f32, vp], C.c_int),
         "adc_check_win_brackets": ([i64, vp, vp, vp, vp, vp, vp, vp], i64),
+        "adc_sample_random_keyword": ([C.c_uint64, C.c_uint32, C.c_uint32, vp], C.c_int),
         "adc_debug_win_brackets_device": ([C.c_int, i64, vp, vp, vp, vp, vp], C.c_int),
         "adc_debug_philox_device": ([C.c_int, i64, vp, vp, vp], C.c_int),
         "adc_debug_walk_stats": ([vp, vp, C.c_int], C.c_int),

@@ -885,6 +885,69 @@ ADC_HD void generate_implicit_keyword(uint64_t key, uint32_t kw, uint32_t serial
     out[7] = rp_sd > 0.01f ? rp_sd : 0.01f;
 }
 
+// ---- keyword-set generation on the device, EXPLICIT model (law of sample_random_keywords, adcraft/gymnasium_kw_utils.py:113-156:
+// the default-constructor keyword set) -------------------------------------------------------------------------------------
+// Every Beta the reference draws there has small integer parameters - (2,5), (5,2), (5,5) - and Beta(a, b) with integer a, b is the
+// a-th smallest of a + b - 1 independent uniforms: exact, no rejection loop, no transcendental.  The uniforms are the top 24 bits
+// of Philox words (rng.random()'s grid is finer; both are far below any float32 parameter's resolution), so an order statistic
+// is itself a 24-bit integer i and the variate is i 2^-24.
+template <int N, int KTH>
+ADC_HD uint32_t order_statistic24(const uint32_t *w)          // the KTH smallest (1-based) of w[0..N-1] >> 8
+{
+    uint32_t pick = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t x = w[i] >> 8;
+        int rank = 0;                                         // elements before x in a stable ascending sort
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const uint32_t y = w[j] >> 8;
+            rank += (y < x || (y == x && j < i)) ? 1 : 0;
+        }
+        if (rank == KTH - 1) pick = x;
+    }
+    return pick;
+}
+// vol_mean = int(2^x 15 - 1) for x = i 2^-24 (gymnasium_kw_utils.py:129-131; B-8: always 14..28) without evaluating 2^x:
+// the value is 14 + #{m in 15..28 : i >= ceil(log2((m + 1) / 15) 2^24)} - the thresholds below, checked against numpy's own float64
+// expression on both sides of every boundary (tests/test_oracle_scalar.py)
+constexpr int kExplicitVolSteps = 14;
+ADC_HD int32_t explicit_vol_mean_from_i24(uint32_t i)
+{
+    const uint32_t T[kExplicitVolSteps] = {1562117u, 3029500u, 4412986u, 5721651u, 6963174u, 8144111u, 9270101u, 10346029u, 11376159u,
+                                           12364231u, 13313546u, 14227028u, 15107285u, 15956650u};
+    int32_t v = 14;
+#pragma unroll
+    for (int m = 0; m < kExplicitVolSteps; ++m) v += i >= T[m] ? 1 : 0;
+    return v;
+}
+constexpr uint32_t kExplicitKeygenFirstCall = 16u;            // (calls 0..3 of ST_KEYGEN belong to generate_implicit_keyword)
+constexpr int kExplicitKeygenCalls = 13;
+// out[8] in adc_param order: vol_mean, vol_std, impression intercept, impression slope, bctr, sctr, rev_mean, rev_std.
+// Words (call c word h = index 4 c + h): 0..5 vol_mean ~ Beta(2,5) | 6 vol_std's uniform | 7 the intercept's | 8..13 sctr ~ Beta(5,2) |
+// 16..21 rev_mean ~ 1.5 Beta(2,5) | 24..29 rev_std / rev_mean ~ Beta(2,5) | 32..37 bctr ~ Beta(2,5) | 40..48 slope ~ 25 Beta(5,5)
+ADC_HD void generate_explicit_keyword(uint64_t key, uint32_t kw, uint32_t serial, float out[8])
+{
+    const uint32_t c3 = 0xFFFF0000u | (serial & 0xFFFFu);
+    uint32_t w[4 * kExplicitKeygenCalls];
+#pragma unroll
+    for (int c = 0; c < kExplicitKeygenCalls; ++c) {
+        const U4 q = philox4x32(kExplicitKeygenFirstCall + (uint32_t)c, ST_KEYGEN, kw, c3, (uint32_t)key, (uint32_t)(key >> 32));
+        w[4 * c] = q.x; w[4 * c + 1] = q.y; w[4 * c + 2] = q.z; w[4 * c + 3] = q.w;
+    }
+    const float scale24 = 5.9604644775390625e-08f;
+    const int32_t vm = explicit_vol_mean_from_i24(order_statistic24<6, 2>(w));                 // :129-131
+    out[0] = (float)vm;
+    out[1] = (unit_closed24(w[6]) * 0.5f) * (float)(vm + 1);                                    // :133
+    out[5] = (float)order_statistic24<6, 5>(w + 8) * scale24;                                   // :135 sctr
+    out[2] = unit_closed24(w[7]) * 1.5f;                                                        // :136 imp_intercept
+    const float mu = ((float)order_statistic24<6, 2>(w + 16) * scale24) * 1.5f;                // :137
+    out[6] = mu;
+    out[7] = ((float)order_statistic24<6, 2>(w + 24) * scale24) * mu;                          // :138
+    out[4] = (float)order_statistic24<6, 2>(w + 32) * scale24;                                  // :139 bctr
+    out[3] = ((float)order_statistic24<9, 5>(w + 40) * scale24) * 25.0f;                       // :140 imp_slope
+}
+
 // the 24-way split of a day's volume, adcraft/bidding_simulation.py:151-167
 ADC_HD void cell_range(int32_t V, int t, int32_t &j0, int32_t &n)
 {

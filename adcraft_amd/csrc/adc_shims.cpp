@@ -164,3 +164,11 @@ ADC_EXPORT int64_t adc_check_win_brackets(int64_t n, const float *bid, const flo
     if (ambiguous_words) *ambiguous_words = amb;
     return bad;
 }
+
+// adcraft/gymnasium_kw_utils.py:113-156 (sample_random_keywords), one keyword: what k_generate_explicit_keywords writes
+ADC_EXPORT int adc_sample_random_keyword(uint64_t key, uint32_t keyword, uint32_t serial, float *out8)
+{
+    if (!out8) return ADC_EINVAL;
+    adc::generate_explicit_keyword(key, keyword, serial, out8);
+    return ADC_OK;
+}

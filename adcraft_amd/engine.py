@@ -177,6 +177,12 @@ class StepEngine:
         m = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8)
         check(self._lib.adc_engine_generate_keywords(self._h, C.byref(q), float(no_vol_prob), int(serial), ptr(m)))
 
+    def generate_explicit_keywords(self, env_mask=None, serial=0):
+        """draw every (masked) env's EXPLICIT keyword set on the device: the law of sample_random_keywords
+        (gymnasium_kw_utils.py:113-156), from each env's own Philox key; see adc_engine_generate_explicit_keywords"""
+        m = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8)
+        check(self._lib.adc_engine_generate_explicit_keywords(self._h, int(serial), ptr(m)))
+
     def set_limits(self, max_days, loss_threshold):
         check(self._lib.adc_engine_set_limits(self._h, int(max_days), float(loss_threshold)))
         self.max_days = int(max_days)
@@ -609,6 +615,10 @@ class ShardedStepEngine:
     def generate_keywords(self, table, no_vol_prob=0.0, env_mask=None, serial=0):
         for p, b0, b1 in self._each():
             p.generate_keywords(table, no_vol_prob, None if env_mask is None else np.asarray(env_mask)[b0:b1], serial)
+
+    def generate_explicit_keywords(self, env_mask=None, serial=0):
+        for p, b0, b1 in self._each():
+            p.generate_explicit_keywords(None if env_mask is None else np.asarray(env_mask)[b0:b1], serial)
 
     def set_limits(self, max_days, loss_threshold):
         for p in self.parts:

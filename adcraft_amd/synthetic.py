@@ -35,3 +35,19 @@ def implicit_keyword_planes(num_envs, num_keywords, seed, mean_volume=128, cvr=0
     mu = _pl(rng, 0.3, 1.0, 1.5, shape)
     sd = np.maximum(0.01, _pl(rng, 0.01, 0.15, 0.3, shape) * mu)
     return np.stack([vol_mean, vol_std, loc, scale, bctr, sctr, mu, sd]).astype(np.float32)
+
+
+def explicit_keyword_planes(num_envs, num_keywords, seed):
+    """float32 [8][N][K] in adc_param order: the law of sample_random_keywords (adcraft/gymnasium_kw_utils.py:129-140: the
+    default-constructor, EXPLICIT keyword set), its eight draws in its order, for all envs at once"""
+    rng = np.random.default_rng(seed)
+    shape = (num_envs, num_keywords)
+    vol_mean = (2 ** rng.beta(2, 5, size=shape) * 15 - 1).astype(int)
+    vol_std = rng.random(size=shape) * 0.5 * (vol_mean + 1)
+    sctr = rng.beta(5, 2, size=shape)
+    intercept = rng.random(size=shape) * 1.5
+    rev_mean = rng.beta(2, 5, size=shape) * 1.5
+    rev_std = rng.beta(2, 5, size=shape) * rev_mean
+    bctr = rng.beta(2, 5, size=shape)
+    slope = rng.beta(5, 5, size=shape) * 25
+    return np.stack([vol_mean, vol_std, intercept, slope, bctr, sctr, rev_mean, rev_std]).astype(np.float32)

@@ -33,7 +33,8 @@ class BiddingSimulationVectorEnv:
         """param_sampler: "reference" draws every env's keywords with the reference's exact seeded recipe
         (env i uses seed + i; host loop, fine up to a few thousand envs); "device" draws the same law on the GPU
         from each env's own Philox key (no host loop, no upload; use it for 10^4+ envs); "vectorised" draws the
-        same law for all envs at once with numpy.
+        same law for all envs at once with numpy.  All three serve both keyword models (keyword_config given: IMPLICIT keywords from
+        the quantile tables; not given: the default constructor's EXPLICIT set, sample_random_keywords).
         engine_shards: the envs are held by this many engines on the device, stepped together so that one part's PCIe
         transfers overlap another's kernels (None: 4 from 2^18 keywords up, else 1); results do not depend on it.
         compact_counts: the three count observations cross PCIe as uint16 (packed on the device: 14 B instead of 20 B per
@@ -88,8 +89,8 @@ class BiddingSimulationVectorEnv:
         N, K = self.num_envs, self.num_keywords
         base = int(np.random.SeedSequence().entropy % (2**62)) if seed is None else int(seed)
         if self.param_sampler == "vectorised":
-            if not self._implicit:
-                raise NotImplementedError("vectorised sampling is provided for keyword_config (implicit) envs")
+            if not self._implicit:      # the default constructor's keyword set: sample_random_keywords' eight draws for all envs at once
+                return synthetic.explicit_keyword_planes(N, K, base + self._env_id_base), base
             kc = self.keyword_config
             return synthetic.implicit_keyword_planes(N, K, base + self._env_id_base,
                                                      mean_volume=kc.get("mean_volume", 128),
@@ -110,14 +111,15 @@ class BiddingSimulationVectorEnv:
         eng = self._ensure_engine(seed)
         if seed is not None or not self._have_keywords:
             if self.param_sampler == "device":
-                if not self._implicit:
-                    raise NotImplementedError("device sampling is provided for keyword_config (implicit) envs")
                 base = int(np.random.SeedSequence().entropy % (2**62)) if seed is None else int(seed)
                 seeds = (np.arange(self.num_envs, dtype=np.uint64) + np.uint64(base + self._env_id_base))
                 eng.reset(seeds=seeds)
-                kc = self.keyword_config
-                load = kc.get("load_quant_func")
-                eng.generate_keywords(load(kc), kc.get("no_vol_prob", 0.0))
+                if self._implicit:
+                    kc = self.keyword_config
+                    load = kc.get("load_quant_func")
+                    eng.generate_keywords(load(kc), kc.get("no_vol_prob", 0.0))
+                else:                   # the default constructor: sample_random_keywords' law (gymnasium_kw_utils.py:113-156)
+                    eng.generate_explicit_keywords()
             else:
                 planes, base = self._sample_planes(seed)
                 eng.set_all_params(planes)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADC_ABI_VERSION 4
+#define ADC_ABI_VERSION 5
 /* revision of the engine's own random stream (which variate lives at which Philox counter): results under a
  * fixed seed - and golden streams recorded from an engine - are comparable only between libraries of the same revision.
  * 2: IMPLICIT / EXPLICIT layout since round 2; 3, 4: IMPLICIT_GENERAL top bids as order statistics, bidder count by inversion */
@@ -187,6 +187,13 @@ int adc_engine_set_env_params(adc_engine *e, int env, const float *host_8k);
  * generating host-side and uploading with adc_engine_set_params). */
 int adc_engine_generate_keywords(adc_engine *e, const adc_quantiles *q, float no_vol_prob, uint32_t serial,
                                  const uint8_t *env_mask);
+
+/* the same for the EXPLICIT model (the default constructor's keyword set): the law of sample_random_keywords
+ * (gymnasium_kw_utils.py:113-156, draws :129-140) - vol_mean = int(2^Beta(2,5) 15 - 1), vol_std = U 0.5 (vol_mean + 1),
+ * sctr ~ Beta(5,2), intercept = 1.5 U, rev_mean = 1.5 Beta(2,5), rev_std = Beta(2,5) rev_mean, bctr ~ Beta(2,5),
+ * slope = 25 Beta(5,5) - from the env's own Philox key; every Beta is an order statistic of uniforms (integer parameters: exact).
+ * Same law, not the reference's PCG64 numbers (those: sample host-side, adc_engine_set_params). */
+int adc_engine_generate_explicit_keywords(adc_engine *e, uint32_t serial, const uint8_t *env_mask);
 
 /* reset(): day=0, cumulative_profit=0 for envs with env_mask[e]!=0 (NULL = all);
  * seeds (nullable, [N]) re-key the env's random stream (reset(seed=...)); gymnasium_kw_env.py:271-346 */
@@ -432,6 +439,10 @@ int adc_auction_word_intervals(float bid, float cost_loc, float cost_scale, floa
 int adc_auction_word_brackets(float bid, float cost_loc, float cost_scale, float buyside_ctr, uint32_t *out8);
 int64_t adc_check_win_brackets(int64_t n, const float *bid, const float *cost_loc, const float *cost_scale, const float *buyside_ctr,
                                const uint32_t *brackets8, int64_t *first_bad, double *ambiguous_words);
+/* one keyword of the default constructor's keyword set, on the host: exactly what adc_engine_generate_explicit_keywords writes for
+ * keyword `keyword` of an env whose Philox key is `key` (adc_engine_get_rng_state) - sample_random_keywords' law
+ * (gymnasium_kw_utils.py:113-156); out8 in adc_param order */
+int adc_sample_random_keyword(uint64_t key, uint32_t keyword, uint32_t serial, float *out8);
 /* diagnostic: the stream's generator (Philox4x32, the stream's round count) evaluated on the device for n counters ctr4[n][4]
  * and keys key2[n][2] -> out4[n][4]; tests compare it with the CPU battery's generator (oracle/stream_battery.c) */
 int adc_debug_philox_device(int device_id, int64_t n, const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);

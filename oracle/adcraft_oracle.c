@@ -1012,4 +1012,51 @@ ORC_API void orc_generate_implicit_keywords(int32_t N, int32_t K, const uint64_t
         }
 }
 
+/* ---- keyword-set generation, EXPLICIT model: Philox form of sample_random_keywords (gymnasium_kw_utils.py:113-156) ----
+ * Its Betas all have small integer parameters - (2,5), (5,2), (5,5) - and Beta(a, b) with integer a, b is the a-th smallest of
+ * a + b - 1 independent uniforms.  Uniforms are the top 24 bits of Philox words, so every variate is i / 2^24. */
+static int cmp_u32(const void *a, const void *b)
+{
+    const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y ? 1 : 0;
+}
+static uint32_t order_statistic24(const uint32_t *w, int n, int kth)      /* the kth smallest (1-based) of w[0..n-1] >> 8 */
+{
+    uint32_t v[16];
+    for (int i = 0; i < n; ++i) v[i] = w[i] >> 8;
+    qsort(v, (size_t)n, sizeof(uint32_t), cmp_u32);
+    return v[kth - 1];
+}
+/* int(2^x 15 - 1) for x = i / 2^24, :129-131, evaluated as the reference does (float64 pow; the device counts thresholds) */
+ORC_API int32_t orc_explicit_vol_mean_from_i24(uint32_t i)
+{
+    return (int32_t)(pow(2.0, (double)i / 16777216.0) * 15.0 - 1.0);
+}
+/* params: [8][N][K] planes (vol_mean, vol_std, intercept, slope, bctr, sctr, rev_mean, rev_std), written for every env */
+ORC_API void orc_generate_explicit_keywords(int32_t N, int32_t K, const uint64_t *key, uint32_t serial, float *params)
+{
+    const uint32_t c3 = 0xFFFF0000u | (serial & 0xFFFFu);
+    const float s24 = 5.9604644775390625e-08f;
+    for (int e = 0; e < N; ++e)
+        for (int k = 0; k < K; ++k) {
+            uint32_t w[52];
+            for (uint32_t i = 0; i < 13; ++i) {
+                uint32_t c[4] = { 16u + i, ST_KEYGEN, (uint32_t)k, c3 }, kk[2] = { (uint32_t)key[e], (uint32_t)(key[e] >> 32) };
+                orc_philox4x32(c, kk, w + 4 * i);
+            }
+            float out[8];
+            const int32_t vm = orc_explicit_vol_mean_from_i24(order_statistic24(w, 6, 2));       /* :129-131 beta(2, 5) */
+            out[0] = (float)vm;
+            out[1] = (u24(w[6]) * 0.5f) * (float)(vm + 1);                                      /* :133 */
+            out[5] = (float)order_statistic24(w + 8, 6, 5) * s24;                               /* :135 beta(5, 2) */
+            out[2] = u24(w[7]) * 1.5f;                                                          /* :136 */
+            const float mu = ((float)order_statistic24(w + 16, 6, 2) * s24) * 1.5f;             /* :137 */
+            out[6] = mu;
+            out[7] = ((float)order_statistic24(w + 24, 6, 2) * s24) * mu;                       /* :138 */
+            out[4] = (float)order_statistic24(w + 32, 6, 2) * s24;                              /* :139 */
+            out[3] = ((float)order_statistic24(w + 40, 9, 5) * s24) * 25.0f;                    /* :140 beta(5, 5) */
+            for (int p = 0; p < 8; ++p) params[((size_t)p * N + e) * K + k] = out[p];
+        }
+}
+
 ORC_API int32_t orc_abi_version(void) { return 1; }

@@ -87,7 +87,7 @@ def build_shims_host(sanitize=False):
     deps = [SHIMS_SRC, os.path.join(os.path.dirname(SHIMS_SRC), "adc_law.h")]
     if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra",
-                               "-Wno-unused-function"] + (SAN_FLAGS if sanitize else ["-O2"]) + [SHIMS_SRC, "-o", out, "-lm"])
+                               "-Wno-unused-function", "-Wno-unknown-pragmas"] + (SAN_FLAGS if sanitize else ["-O2"]) + [SHIMS_SRC, "-o", out, "-lm"])
     return out
 
 

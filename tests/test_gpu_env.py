@@ -3,6 +3,7 @@ The first block mirrors the reference's own env tests (adcraft/tests/test_env.py
 import numpy as np
 import pytest
 
+from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
@@ -404,6 +405,68 @@ def test_device_keyword_generation_matches_oracle_and_reference_law(pkg):
         assert stats.ks_2samp(got[p].ravel(), host[p].ravel()).pvalue > 1e-4, p
     assert abs((got[0] == 0).mean() - 0.3) < 0.01
     e.close()
+
+
+def test_device_explicit_keyword_generation_matches_oracle_and_reference_law(pkg):
+    """f3, the other generator: sample_random_keywords (gymnasium_kw_utils.py:113-156) on the device - k_generate_explicit_keywords ==
+    the oracle's restatement bit for bit (all eight planes, masked envs untouched, a second serial differs), every plane against
+    numpy's beta / random at n = 2.6e5 (two-sample KS), vol_mean in B-8's range"""
+    from scipy import stats
+    from adcraft_amd.engine import StepEngine
+    from tests.test_keygen_explicit import oracle_planes
+    N, K = 512, 512
+    e = StepEngine(N, K, model=1, seed=3)
+    e.reset(seeds=np.arange(N, dtype=np.uint64) + np.uint64(4000))
+    e.generate_explicit_keywords()
+    got = e.get_all_params()
+    keys, _ = e.get_rng_state()
+    assert np.array_equal(got, oracle_planes(keys, K, 0))
+    mask = np.zeros(N, np.uint8)
+    mask[::3] = 1
+    e.generate_explicit_keywords(env_mask=mask, serial=1)
+    again = e.get_all_params()
+    ref1 = oracle_planes(keys, K, 1)
+    assert np.array_equal(again[:, mask == 1], ref1[:, mask == 1]) and np.array_equal(again[:, mask == 0], got[:, mask == 0])
+    assert not np.array_equal(ref1[:, mask == 1], got[:, mask == 1])
+    host = H.explicit_params(N, K, seed=99).reshape(8, -1)
+    for p in range(8):
+        assert stats.ks_2samp(got[p].ravel(), host[p]).pvalue > 1e-3, p
+    assert got[0].min() >= 14 and got[0].max() <= 29
+    # the engine steps on them (the default-constructor model) and equals the oracle on the generated planes
+    o = H.mirror_oracle(e, again)
+    bids = o.sample_bids(0.3, 1.0)
+    H.assert_step_equal(e.step(bids, 1.0e9), o.step(bids, 1.0e9), implicit=False)
+    e.close()
+    # an IMPLICIT engine refuses (its keywords come from quantile tables)
+    e = StepEngine(2, 8, model=0, seed=1)
+    e.reset(seeds=np.arange(2, dtype=np.uint64))
+    with pytest.raises((ValueError, AssertionError)):
+        e.generate_explicit_keywords()
+    e.close()
+
+
+def test_default_constructor_vector_env_resets_on_the_device(pkg):
+    """a 4096-env default-constructor BiddingSimulationVectorEnv(param_sampler="device") resets without a host loop; the
+    vectorised host sampler draws the same law"""
+    from scipy import stats
+    from adcraft_amd.vector_env import BiddingSimulationVectorEnv
+    vec = BiddingSimulationVectorEnv(4096, num_keywords=64, param_sampler="device")
+    vec.reset(seed=5)
+    p1 = vec.engine.get_all_params()
+    assert p1[0].min() >= 14 and p1[0].max() <= 29 and 0.0 <= p1[4].min() and p1[5].max() <= 1.0
+    obs, rew, term, trunc, _ = vec.step({"keyword_bids": np.full((4096, 64), 0.8, np.float32)})
+    assert obs["impressions"].shape == (4096, 64) and obs["impressions"].sum() > 0 and rew.shape == (4096,)
+    vec.reset(seed=5)
+    assert np.array_equal(vec.engine.get_all_params(), p1)          # same seed, same keyword sets
+    vec.reset(seed=6)
+    assert not np.array_equal(vec.engine.get_all_params(), p1)
+    vec.close()
+    host = BiddingSimulationVectorEnv(4096, num_keywords=64, param_sampler="vectorised")
+    host.reset(seed=5)
+    p2 = host.engine.get_all_params()
+    for p in range(8):
+        assert stats.ks_2samp(p1[p].ravel(), p2[p].ravel()).pvalue > 1e-3, p
+    host.close()
 
 
 def test_vector_env_device_sampler(pkg):

@@ -638,6 +638,112 @@ def test_g12_general_implicit_replay_on_gpu(amd, golden):
         e.close()
 
 
+def test_g12_outcome_lists_on_gpu_element_for_element(amd, golden):
+    """the default ImplicitKeyword's per-click lists against the reference's own combined BiddingOutcomes (G12, recorded by
+    tools/gen_golden_general.py): step_replay on the reference's tape, the read-only walk of the same tape
+    (adc_engine_outcomes_replay_tape, model 2) and the facade's combination - float64 prices and revenues element for element
+    and in order, impression_share the very float64, profit within 1e-9"""
+    from adcraft_amd.gymnasium_kw_env import combined_outcomes
+    n = 0
+    for t in golden("g12_implicit_general_replay.json")["traces"]:
+        K, tp = t["K"], t["tape"]
+        e = amd.StepEngine(1, K, model=2, seed=1)
+        e.set_general_model(t["max_bidders"], t["participation_rate"], 1)
+        planes = np.zeros((8, 1, K), np.float32)
+        for i, name in ((2, "bid_loc"), (3, "bid_scale"), (4, "bctr"), (5, "sctr"), (6, "rev_mean"), (7, "rev_std")):
+            planes[i, 0] = [p[name] for p in t["keyword_params"]]
+        e.set_all_params(planes)
+        e.reset()
+
+        def tape():
+            return amd.ReplayTape(1, np.array(t["volumes"]).reshape(1, K), click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"],
+                                  x_impressions=tp["bidders"], x_cost=tp["bids"])
+        bids = np.array(t["bids"], np.float32)
+        out = e.step_replay(bids, t["budget"], tape())
+        clicks = e.outcomes_replay(0, bids, t["budget"], tape=tape())
+        obs = {k: out[k][0] for k in ("impressions", "buyside_clicks", "sellside_conversions", "cost", "revenue")}
+        rows = combined_outcomes(t["bids"], obs, clicks)
+        H.assert_outcome_lists({f: [r[f] for r in rows] for f in ("costs", "revenues", "revenues_per_cost", "impression_share", "profit")},
+                               t["out"], K)
+        assert [r["buyside_clicks"] for r in rows] == t["out"]["buyside_clicks"] == [len(c) for c in t["out"]["costs"]]
+        n += sum(t["out"]["buyside_clicks"])
+        e.close()
+    assert n > 1000
+
+
+def _model_case(model, rng, N, K):
+    """keyword planes, bid range, (ample, binding) budgets and engine / oracle settings of a small case per model"""
+    if model == 0:
+        return H.implicit_params(N, K, seed=77, mean_volume=40), (0.3, 1.0), (1.0e9, 30.0), {}
+    if model == 1:
+        return H.explicit_params(N, K, seed=78), (0.3, 1.0), (1.0e9, 25.0), {}
+    planes = np.stack([rng.integers(0, 90, (N, K)), rng.random((N, K)) * 6, rng.uniform(0.0, 0.3, (N, K)), rng.uniform(0.05, 0.15, (N, K)),
+                       rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.3, 1.5, (N, K)),
+                       rng.uniform(0.02, 0.3, (N, K))]).astype(np.float32)
+    return planes, (0.05, 0.5), (1.0e9, 3.0), dict(max_bidders=30, participation_rate=0.6, num_winners=1)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+@pytest.mark.parametrize("drift", [False, True])
+@pytest.mark.parametrize("binding", [False, True])
+def test_production_outcomes_replay_matches_oracle_click_for_click(amd, model, drift, binding):
+    """info["bidding_outcomes"] as production builds it: adc_engine_outcomes_replay on the engine's OWN stream (the PHILOX
+    instantiation of the read-only walk, addressed at tick - steps_back) against the oracle's orc_step_outcomes(tape = NULL) - every
+    paid click's keyword, sub-timestep, cost and revenue in the reference's order (bidding_simulation.py:97-115,216-233), and the
+    combined costs / revenues / revenues_per_cost / impression_share / profit per keyword (:124-147); for every env of the
+    engine, with and without drift, binding and ample budgets, the last step and (drift off) the one before it."""
+    from adcraft_amd.gymnasium_kw_env import combined_outcomes
+    N, K = 3, 40
+    rng = np.random.default_rng(100 + model)
+    planes, (blo, bhi), budgets, general = _model_case(model, rng, N, K)
+    budget = budgets[1] if binding else budgets[0]
+    e = amd.StepEngine(N, K, model=model, seed=21 + model, drift_enabled=drift)
+    if model == 2:
+        e.set_general_model(general["max_bidders"], general["participation_rate"], general["num_winners"])
+    e.set_all_params(planes)
+    e.reset()
+    o = H.mirror_oracle(e, planes, drift_on=drift, **general)
+    n_clicks = n_bound = 0
+    history = []
+    for step in range(4):
+        bids = o.sample_bids(blo, bhi)
+        got = e.step(bids, budget)
+        ref, lists = o.step_outcomes(bids, budget)
+        H.assert_step_equal(got, ref, implicit=(model == 0))
+        history.append((bids, got, lists))
+        for back in ((1,) if drift else (1, 2)):
+            if back > len(history):
+                continue
+            b_bids, b_got, b_lists = history[-back]
+            for env in range(N):
+                before = e.get_episode_state()
+                clicks = e.outcomes_replay(env, b_bids[env], budget, steps_back=back)
+                after = e.get_episode_state()
+                assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])        # read-only
+                sel = b_lists["env"] == env
+                assert np.array_equal(clicks["keyword"], b_lists["keyword"][sel])
+                assert np.array_equal(clicks["timestep"], b_lists["timestep"][sel])
+                assert np.array_equal(clicks["cost"], b_lists["cost"][sel])               # float64 dollars, bit for bit
+                assert np.array_equal(clicks["revenue"], b_lists["revenue"][sel])
+                obs = {k: b_got[k][env] for k in ("impressions", "buyside_clicks", "sellside_conversions", "cost", "revenue")}
+                rows = combined_outcomes(b_bids[env].tolist(), obs, clicks)
+                want = dict(costs=b_lists["costs"][env], revenues=b_lists["revenues"][env], revenues_per_cost=b_lists["revenues_per_cost"][env],
+                            impression_share=b_lists["impression_share"][env].tolist(), profit=b_lists["profit"][env].tolist())
+                H.assert_outcome_lists({f: [r[f] for r in rows] for f in ("costs", "revenues", "revenues_per_cost", "impression_share", "profit")},
+                                       want, K)
+                assert [r["buyside_clicks"] for r in rows] == [len(c) for c in want["costs"]]
+                if back == 1:
+                    n_clicks += int(sel.sum())
+        spent = ref["cost_cents"].sum(axis=1) / 100.0 if model == 0 else ref["cost"].sum(axis=1)
+        n_bound += int((spent > 0.8 * budget).sum())
+    assert n_clicks > 50
+    assert (n_bound >= N) if binding else (n_bound == 0)
+    if drift:
+        o.materialize_drift()
+        assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+
+
 @pytest.mark.parametrize("small", ["0", "1"])
 @pytest.mark.parametrize("budget,winners,pool", [(1e9, 1, (30, 0.6)), (3.0, 1, (30, 0.6)), (1e9, 2, (30, 0.6)), (1e9, 1, (3, 0.4)), (2.0, 2, (70, 0.5)),
                                                  (1e9, 1, (120, 0.97))])

@@ -211,6 +211,32 @@ def test_g12_general_implicit_replay(golden):
     assert any(t["budget"] < 1e8 and sum(t["out"]["buyside_clicks"]) > 0 for t in g["traces"])
 
 
+def _g12_oracle(t):
+    K = t["K"]
+    eng = orc.OracleEngine(1, K, model=orc.IMPLICIT_GENERAL, max_bidders=t["max_bidders"], participation_rate=t["participation_rate"])
+    kp = t["keyword_params"]
+    for plane, name in ((2, "bid_loc"), (3, "bid_scale"), (4, "bctr"), (5, "sctr"), (6, "rev_mean"), (7, "rev_std")):
+        eng.params[plane, 0] = [p[name] for p in kp]
+    tp = t["tape"]
+    tape = orc.TapeSource(click=tp["click"], conv=tp["conv"], rev_cents=tp["rev"], x_impressions=tp["bidders"], x_cost=tp["bids"])
+    tape.set_volumes(np.array(t["volumes"]).reshape(1, K))
+    return eng, tape
+
+
+def test_g12_outcome_lists_element_for_element(golden):
+    """the default ImplicitKeyword's combined BiddingOutcomes (bidding_simulation.py:10-38,124-147) as the reference recorded them
+    (tools/gen_golden_general.py): every click's float64 price and revenue in order, impression_share with the lossy denominator"""
+    from tests import helpers as H
+    n = 0
+    for t in golden("g12_implicit_general_replay.json")["traces"]:
+        eng, tape = _g12_oracle(t)
+        o, lists = eng.step_outcomes(np.array(t["bids"], dtype=np.float32), t["budget"], tape, capacity=32)
+        H.assert_outcome_lists(lists, t["out"], t["K"])
+        assert [len(c) for c in lists["costs"][0]] == t["out"]["buyside_clicks"]
+        n += sum(t["out"]["buyside_clicks"])
+    assert n > 1000
+
+
 def test_general_implicit_stream_law():
     """the engine's own stream for that model: bidders per call ~ Binomial(30, 0.6), the winning price is the highest raw
     Laplace(0, 0.1) competitor bid - checked on the win rate and the mean price at a given bid against a numpy simulation of

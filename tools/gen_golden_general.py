@@ -97,7 +97,8 @@ def main():
                      sellside_conversions=[int(o["sellside_conversions"]) for o in outcomes],
                      cost=[G.rust_sum_list(o["costs"]) for o in outcomes],
                      revenue=[float(np.sum(np.asarray(o["revenues"], dtype=np.float64))) if len(o["revenues"]) else 0.0 for o in outcomes],
-                     profit=[float(o["profit"]) for o in outcomes])))
+                     profit=[float(o["profit"]) for o in outcomes],
+                     impression_share=[float(o["impression_share"]) for o in outcomes], **G.outcome_lists(outcomes))))
         print(f"seed {seed}: {sum(vols)} auctions, {len(tape['bidders'])} cells visited, {len(tape['bids'])} bids, "
               f"impressions {sum(traces[-1]['out']['impressions'])}, clicks {sum(traces[-1]['out']['buyside_clicks'])}")
     G.dump("g12_implicit_general_replay.json", dict(
@@ -106,7 +107,8 @@ def main():
                "bids, nth_price_auction with n=2, num_winners=1), executed unmodified; tapes in call order (t-major, keyword-"
                "minor): bidders = one count per visited cell; bids = float64 bids, bidders x auctions per cell, bidder-major as "
                "bid_distribution(s, n) returns them; click = one boolean per won auction; conv = one per paid click; rev = "
-               "revenue in cents per conversion",
+               "revenue in cents per conversion; out.costs / revenues / revenues_per_cost / impression_share: the combined outcomes' "
+               "per-click lists and combine_outcomes' impression_share (bidding_simulation.py:10-38,124-147), as in g3_implicit_replay",
         traces=traces))
 
 
