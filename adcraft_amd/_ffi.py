@@ -19,6 +19,12 @@ class EngineError(RuntimeError):
     pass
 
 
+class EngineStateError(AssertionError):
+    """ADC_ESTATE: the call is not valid in the engine's current state (step before reset, a step whose clicks can no longer be
+    replayed ...).  An AssertionError, as the reference raises for step-before-reset (gymnasium_kw_env.py:194-196), but one of its
+    own type, so that callers can tell it from a genuine Python `assert` failing."""
+
+
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device_id", C.c_int32), ("num_envs", C.c_int32),
                 ("num_keywords", C.c_int32), ("model", C.c_int32), ("max_days", C.c_int32),
@@ -187,7 +193,7 @@ def check(rc):
     if rc == ADC_EINVAL:
         raise ValueError(msg)
     if rc == ADC_ESTATE:
-        raise AssertionError(msg)          # gymnasium_kw_env.py:194-196 asserts on step-before-reset
+        raise EngineStateError(msg)        # (an AssertionError: gymnasium_kw_env.py:194-196 asserts on step-before-reset)
     if rc == ADC_ENOMEM:
         raise MemoryError(msg)
     if rc == ADC_ETYPE:

@@ -28,6 +28,18 @@ def _deps():
     return [p for p in out if os.path.exists(p)]
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the library's sources in a fixed order: what tools/pmc_collect.py stores next to its counters
+    and bench.py compares, so that counters taken on other kernels are not quoted as this build's"""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(_deps()):
+        h.update(os.path.relpath(p, ROOT).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

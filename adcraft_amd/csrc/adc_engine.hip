@@ -23,9 +23,6 @@
 //        host's volume hint): auctions classified against conservative win BRACKETS (float estimates with a guaranteed
 //        slack; the ~2e-5 of words in between take the long way), work items located through a byte list in LDS,
 //        parameters / env header / metric sums software-pipelined across the tiles of a workgroup.
-//   parts/kernel_sparse_wave.inc  k_step_implicit_sparse_wave<KPL> (round 4) - the sparse pass with one wavefront per tile and 2 or 4
-//        consecutive keywords per lane (8- / 16-byte accesses), LDS records for live keywords only, no workgroup barrier after the
-//        tables are loaded; the kernel above remains for keyword counts that are not a multiple of KPL.
 //   parts/kernel_exact_rows.inc   k_step_exact_rows - one workgroup per env: envs whose fast-pass spend reached the
 //        budget are re-run in the reference's order, a sub-timestep row of K cells at a time (parallel cell
 //        statistics, budget walk by prefix scans, ring-compacted conversions); then the step tail.
@@ -70,7 +67,6 @@ namespace adck {
 #include "parts/kernel_fast.inc"
 #include "parts/kernel_sparse.inc"
 #include "parts/kernel_exact_rows.inc"
-#include "parts/kernel_sparse_wave.inc"
 #include "parts/kernel_click_walk.inc"
 #include "parts/kernel_exact_serial.inc"
 #include "parts/kernel_explicit_fast.inc"

@@ -26,6 +26,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import gymnasium_kw_utils as utils
+from . import _ffi
 from . import spaces as _spaces
 from ._ffi import MODEL_EXPLICIT, MODEL_IMPLICIT, P_BCTR, P_SCTR, P_VOL_MEAN
 
@@ -329,7 +330,7 @@ class BiddingSimulation(_EnvBase):
         if replayable:
             try:
                 clicks = self._engine.outcomes_replay(0, bids_f32, budget_used, steps_back=back)
-            except AssertionError:          # ADC_ESTATE: the engine itself says this step's clicks are gone (e.g. its drift was applied)
+            except _ffi.EngineStateError:   # ADC_ESTATE only: the engine itself says this step's clicks are gone (e.g. its drift was applied)
                 clicks = None
             return self._repr_outcomes(bids, obs, clicks)
         return self._repr_outcomes(bids, obs, None)

@@ -29,6 +29,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 instruction per 2 cycles per SIMD
+# ... which only packed / pure add-fma streams reach.  A wave64 instruction of the classes these kernels are made of (compares,
+# converts, min / max, integer multiplies, v_cndmask, mbcnt, anything VOP3 with a literal) occupies its SIMD for 4 cycles
+# (profiles/r02_issue_rates.md; the round-4 ablations price the sparse kernel at 4.0-4.3 cycles per instruction): the rate this
+# instruction mix can reach is 16 lanes per SIMD and cycle
+VALU_PEAK_4CYCLE_LANE_OPS = 256 * 4 * 16 * 2.4e9
 BYTES_PER_U = {False: 56, True: 68}   # 36 B read + 20 B written per keyword-step (+12 B drift write-back)
 BYTES_PER_ENV = 26
 MAX_DAYS = 60
@@ -81,9 +86,17 @@ def pmc_notes(cfg_name):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(cfg_name, {})
+            rec = json.load(f).get(cfg_name, {})
     except (OSError, ValueError):
         return {}
+    # counters are quoted only for the library build they were taken on: tools/pmc_collect.py stores the hash of the library's
+    # sources; a record without one, or with another, is older than the kernels and is refused
+    from adcraft_amd import build as hip_build
+    have, want = rec.get("library_source_hash"), hip_build.source_hash()
+    if have != want:
+        return {"stale": f"profiles/pmc_traffic.json[{cfg_name}] was collected on library sources {have}, this build is {want}: "
+                         "PMC figures withheld (re-run tools/pmc_collect.py)"}
+    return rec
 
 
 def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_baseline, collective_alone=False):
@@ -121,6 +134,13 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         eng.step_device()
     red.metric_sums(ideal_k * warmup, ideal_pos_k * warmup)       # also brings the collective path up outside the timed region
     barrier()
+    # (the line also carries what the contract's flags alone measure - K steps right behind the W warm-up steps, before the
+    #  clock spin below - so that the driver-shaped figure stays comparable with rounds that had no spin)
+    t_u = time.perf_counter()
+    for _ in range(steps):
+        eng.step_device()
+    barrier()
+    unspun_ms = (time.perf_counter() - t_u) / steps * 1e3
     # a short timed region starts on clocks that are still ramping (a 20-step region measured 6 % slower than a 200-step one): more
     # UNTIMED steps until the device has been busy for args.spin_seconds; the driver's --warmup steps above stay what they are
     spin_steps, t_spin = 0, time.perf_counter()
@@ -180,13 +200,14 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                     f"{MAX_DAYS}-step episodes with auto-reset",
         "envs_per_gpu": N, "keywords": K,
         "clock_spin_steps": spin_steps,
+        "ms_per_step_before_clock_spin": unspun_ms,
         "timed_region": {"host_ms_per_step": own_elapsed / steps * 1e3, "gpu_ms_per_step": region_gpu_ms / steps,
                          "method": "host clock between two barriers (the contract's figure) | one HIP event pair on the engine's stream "
                                    "around the same region"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": notes.get("hbm_bytes_per_launch"),
-                     "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else None),
+                     "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else notes.get("stale")),
                      "kernel": step_kernel if dom == 0 else KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps,
                      "event_records_in_timed_region": int(records_in_timed_region),
                      "kernel_ms_method": f"HIP events on the engine's stream around every step of a separate, untimed pass of {steps} steps "
@@ -202,10 +223,17 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         # full-rate opcodes (profiles/r02_issue_rates.md: compares, converts, min/max, integer multiplies cost 4 cycles)
         lane_ops = valu["wave_instructions_per_launch"] * 64.0 / (k_ms * 1e-3)
         res["roofline_valu"] = {"bound": "valu", "achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-instructions/s",
-                                "frac": lane_ops / VALU_PEAK_LANE_OPS, "kernel": step_kernel, "kernel_ms": k_ms,
+                                "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                                "peak_4cycle": VALU_PEAK_4CYCLE_LANE_OPS, "frac_4cycle": lane_ops / VALU_PEAK_4CYCLE_LANE_OPS,
+                                "peaks": "peak: one wave64 instruction per 2 cycles per SIMD (packed / pure add-fma streams only); peak_4cycle: "
+                                         "per 4 cycles - what compares, converts, min/max, integer multiplies and selects cost, i.e. the rate "
+                                         "this kernel's instruction mix can reach (profiles/r02_issue_rates.md)",
+                                "kernel": step_kernel, "kernel_ms": k_ms,
                                 "valu_wave_instructions_per_launch": valu["wave_instructions_per_launch"],
                                 "valu_lane_instructions_per_auction": valu.get("valu_lane_instructions_per_auction"),
                                 "source": "instruction count: " + str(notes.get("source_note")) + "; kernel time: HIP events in this run"}
+    elif notes.get("stale"):
+        res["roofline_valu"] = {"bound": "valu", "achieved": None, "frac": None, "note": notes["stale"]}
     if world > 1:
         res["ms_per_step_by_rank"] = [float(x) / steps * 1e3 for x in per_rank]
     if with_collective or collective_error:
@@ -312,7 +340,7 @@ def run_rank(args):
         r = run_config(c, args, rank, world, local_rank, max(60 if c == "cfg4" else 50, min(args.steps, 100)), max(10, min(args.warmup, 20)),
                        with_cpu_baseline=False, collective_alone=(c == "cfg4" and not args.no_collective_alone))
         also[c] = {k: r[k] for k in ("value", "ms_per_step", "steps", "workload", "roofline", "episode_metric", "collective", "timed_region",
-                                     "clock_spin_steps", "ms_per_step_by_rank") if k in r}
+                                     "clock_spin_steps", "ms_per_step_before_clock_spin", "ms_per_step_by_rank") if k in r}
         if "roofline_valu" in r:
             also[c]["roofline_valu"] = r["roofline_valu"]
     if rank == 0:
@@ -333,7 +361,7 @@ def run_rank(args):
             "env_steps_per_s": main["env_steps_per_s"],
             "roofline": main["roofline"],
         }
-        for k in ("timed_region", "clock_spin_steps", "ms_per_step_by_rank", "collective", "roofline_valu", "episode_metric", "cpu_baseline"):
+        for k in ("timed_region", "clock_spin_steps", "ms_per_step_before_clock_spin", "ms_per_step_by_rank", "collective", "roofline_valu", "episode_metric", "cpu_baseline"):
             if k in main:
                 line[k] = main[k]
         if also:

@@ -281,9 +281,12 @@ int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
  * checked against */
 int adc_engine_region_begin(adc_engine *e);
 int adc_engine_region_end(adc_engine *e, double *gpu_ms);
-/* name of the kernel the last step's first pass ran (the one kernel_ms_total[0] times): "k_step_implicit_fast<false>",
- * "k_step_implicit_fast<true>" (narrow tiles), "k_step_implicit_sparse", "k_step_general_fast", "k_step_explicit_fast", or
- * "k_step_exact" after a tape replay; "" before the first step.  A static string: do not free. */
+/* name of the kernel the last step's first pass ran (the one kernel_ms_total[0] times).  IMPLICIT: "k_step_implicit_fast<false>"
+ * (dense keyword sets, 256 keywords per workgroup), "k_step_implicit_fast<true>" (a handful of envs: narrow tiles), either with
+ * ", lists" before the ">" once an env lists its clicked wins for k_step_click_walk ("k_step_implicit_fast<false, lists>"),
+ * "k_step_implicit_sparse" (few auctions per keyword); IMPLICIT_GENERAL: "k_step_general_fast", "k_step_general_small" (a handful
+ * of envs: a wavefront per keyword); EXPLICIT: "k_step_explicit_fast"; "k_step_exact" after a tape replay; "" before the first
+ * step.  A static string: do not free. */
 const char *adc_engine_step_kernel_name(adc_engine *e);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------------------------- */

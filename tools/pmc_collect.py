@@ -33,7 +33,7 @@ for name, counters in PASSES.items():
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 sys.path.insert(0, ".")
-from adcraft_amd import synthetic  # noqa: E402
+from adcraft_amd import build as hip_build, synthetic  # noqa: E402
 N, K, mean_volume, cvr, no_vol_prob, drift = synthetic.CONFIGS[cfg]
 auctions = N * K * mean_volume * (1.0 - no_vol_prob)
 rec = {
@@ -46,7 +46,8 @@ rec = {
              "lds_active_quad_cycles": m["SQ_ACTIVE_INST_LDS"], "grbm_gui_active": m["GRBM_GUI_ACTIVE"], "waves": m["SQ_WAVES"],
              "auctions_per_launch_expected": auctions,
              "valu_lane_instructions_per_auction": m["SQ_INSTS_VALU"] * 64.0 / auctions},
-    "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 4); "
+    "library_source_hash": hip_build.source_hash(),      # bench.py quotes these counters only for the build they were taken on
+    "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 5); "
                    "FETCH_SIZE doubled per the gfx950 correction; bench runs in metric mode (+8 B per keyword-step of accumulator traffic: a 32-bit word read and written)",
 }
 with open(os.path.join(out, f"pmc_{cfg}.json"), "w") as f:
