@@ -52,7 +52,7 @@ class Tape(C.Structure):
 
 
 _lib = None
-ABI_VERSION, STREAM_REVISION = 5, 4           # include/adcraft_engine.h ADC_ABI_VERSION, ADC_STREAM_REVISION
+ABI_VERSION, STREAM_REVISION = 5, 5           # include/adcraft_engine.h ADC_ABI_VERSION, ADC_STREAM_REVISION
 
 
 def library_path():

@@ -10,7 +10,7 @@
 // what lets a CPU restatement reproduce every integer this file produces.
 //
 // What each transform stands for in the reference:
-//   laplace_cents    round2(max(|Laplace(loc,scale)|, 0))   adcraft/synthetic_kw_helpers.py:104-113
+//   competitor_cents_from_v   round2(max(|Laplace(loc,scale)|, 0))   adcraft/synthetic_kw_helpers.py:104-113
 //   bernoulli        rng.random(n) <= p                     adcraft/synthetic_kw_helpers.py:73-77
 //   revenue_cents    round2(max(N(mu,sd), 0.01))            adcraft/synthetic_kw_helpers.py:66-70
 //   volume           round(max(N(mean,sd), 0))              src/lib.rs:314-325
@@ -238,13 +238,6 @@ ADC_HD int32_t money_to_cents(float dollars)
     float c = __builtin_rintf(dollars * 100.0f);
     c = c < kMoneyMaxCents ? c : kMoneyMaxCents;
     return (int32_t)c;
-}
-
-ADC_HD int32_t laplace_cents(uint32_t w, float loc, float scale)
-{
-    const float e = -det_log(unit_open23(w));
-    const float z = sign_bit(w) ? e : -e;
-    return money_to_cents(__builtin_fabsf(fma32(scale, z, loc)));
 }
 
 // event <=> (uint64)word < threshold; threshold = round(p * 2^32) in [0, 2^32]

@@ -34,8 +34,10 @@ extern "C" {
 #define ADC_ABI_VERSION 5
 /* revision of the engine's own random stream (which variate lives at which Philox counter): results under a
  * fixed seed - and golden streams recorded from an engine - are comparable only between libraries of the same revision.
- * 2: IMPLICIT / EXPLICIT layout since round 2; 3, 4: IMPLICIT_GENERAL top bids as order statistics, bidder count by inversion */
-#define ADC_STREAM_REVISION 4
+ * 2: IMPLICIT / EXPLICIT layout since round 2; 3, 4: IMPLICIT_GENERAL top bids as order statistics, bidder count by inversion;
+ * 5: the competitor bids the ideal-profit estimator samples (stage METRIC) by the auction law's own transform of a word (the step's
+ *    own streams are those of revision 4) */
+#define ADC_STREAM_REVISION 5
 
 typedef enum adc_status {
     ADC_OK = 0,

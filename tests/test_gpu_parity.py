@@ -1015,7 +1015,7 @@ def test_ideal_profit_matches_host_restatement(amd):
             cents = []
             for i in range(n // 4):
                 w = orc.philox([i, 6, k, int(ticks[env])], [int(keys[env]) & 0xFFFFFFFF, int(keys[env]) >> 32])
-                cents += [L.orc_laplace_cents_from_word(int(x), float(planes[2, env, k]), float(planes[3, env, k])) for x in w]
+                cents += [L.orc_competitor_cents_from_v(int(x) >> 8, float(planes[2, env, k]), float(planes[3, env, k])) for x in w]      # (stream revision 5)
             ir, cpc = rn.implicit_bid_cpc_impressions(np.array(cents, dtype=np.float64).reshape(1, -1) / 100.0, bids)
             kwp = [[float(planes[0, env, k]), 0.0], 0, 0, float(planes[4, env, k]), float(planes[5, env, k]), float(planes[6, env, k])]
             ref = rn.max_expected_bid_profits(kwp, cpc, ir)[0]
