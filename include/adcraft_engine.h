@@ -451,6 +451,11 @@ int adc_sample_random_keyword(uint64_t key, uint32_t keyword, uint32_t serial, f
 /* diagnostic: the stream's generator (Philox4x32, the stream's round count) evaluated on the device for n counters ctr4[n][4]
  * and keys key2[n][2] -> out4[n][4]; tests compare it with the CPU battery's generator (oracle/stream_battery.c) */
 int adc_debug_philox_device(int device_id, int64_t n, const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);
+/* diagnostic: the reference's float64 budget chain `remaining -= sum(costs)` (bidding_simulation.py:225) over n cell sums x, as the
+ * budget-exact kernels evaluate it - 64 rounded subtractions at a time by an integer prefix scan inside the running value's binade
+ * (parts/common.inc chain_subtract_wave) -> out2[0]; and by the plain chain of n rounded subtractions on the device -> out2[1].
+ * The two are the same float64, bit for bit, for every input. */
+int adc_debug_chain_device(int device_id, double r0, int64_t n, const double *x, double *out2);
 /* counters of k_step_click_walk on the engine's device since the library was loaded (or the last call with reset != 0):
  * stats[0] env-steps walked, [1] handed to the row kernel because the click list overflowed, [2] because the campaign
  * stopped, [3] for another reason (budget <= 0, a keyword-day above 2^22 cents in metric mode).  Test / measurement aid. */

@@ -249,6 +249,64 @@ def test_lazy_allocation_failure_turns_the_path_off_not_the_step(amd, monkeypatc
     e.close()
 
 
+def test_float_chain_by_integer_scan(amd):
+    """The reference's `remaining_budget -= sum(costs)` chain (bidding_simulation.py:225) is float64 arithmetic, rounded after every
+    cell, and its residue decides exact ties (B-15).  The kernels subtract 64 cell sums at a time by an integer prefix scan inside the
+    running value's binade (common.inc chain_subtract_wave).  That must be THE float64 of the plain chain, bit for bit: checked on the
+    device against its own one-lane chain and against numpy's, on random laws and on the cases the scan has to hand to the hardware -
+    exact halves (round-half-even), results that leave the binade, operands as large as the running value, zeros, a chain that
+    runs the value down to (and through) zero, negative and subnormal operands."""
+    import ctypes as C
+    from adcraft_amd import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(77)
+
+    def run(r0, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(2, np.float64)
+        _ffi.check(L.adc_debug_chain_device(0, float(r0), x.size, x.ctypes.data, out.ctypes.data))
+        ref = np.float64(r0)
+        for v in x:
+            ref = ref - v                      # float64, one rounding per step
+        assert out[0].tobytes() == out[1].tobytes() == np.float64(ref).tobytes(), (r0, out, ref)
+        return out[0]
+
+    # the budgets and cell sums the engine meets: cents / 100 in float64, sums of a few of them
+    for trial in range(60):
+        n = int(rng.integers(1, 700))
+        cents = rng.integers(0, 400, (n, 4)) * (rng.random((n, 4)) < 0.4)
+        x = np.zeros(n)
+        for j in range(4):
+            x = x + cents[:, j] / 100.0        # left to right, as a cell's costs are summed
+        run(float(rng.choice([1000.0, 10.0, 37.5, 123456.78, 0.5 + x.sum(), x.sum()])), x)
+    # exact halves of the running value's ulp, on both parities, and just beside them
+    for r0 in (600.0, 600.0 + 2.0 ** -43, 1.0, 2.0 - 2.0 ** -52, 1023.9999999):
+        u = np.spacing(np.float64(r0))
+        base = rng.integers(1, 1 << 20, 300).astype(np.float64) * u
+        for off in (0.5 * u, 0.5 * u + np.spacing(0.5 * u), 0.5 * u - np.spacing(0.25 * u), 0.25 * u, 0.75 * u, 0.0):
+            run(r0, base + off)
+        run(r0, np.full(200, 0.5 * u))                 # nothing but ties
+        run(r0, np.full(200, 1.5 * u))
+    # binade exits: a value ground down over many octaves, operands comparable to it, the last step to exactly zero and below
+    run(1024.0, np.array([512.0, 256.0, 128.0, 64.0, 32.0, 16.0, 8.0, 4.0, 2.0, 1.0, 0.5, 0.25, 0.25, 0.125]))
+    run(1000.0, np.concatenate([np.full(99, 10.0), [9.99, 0.01], [0.01] * 3]))
+    run(5.0, rng.random(500) * 0.02)
+    x = rng.random(640) * 3.0
+    run(float(np.float64(x[:320].sum())), x)                        # crosses zero somewhere in the middle
+    run(1.0e15, rng.random(300) * 1.0e13)
+    run(0.07, np.array([0.01] * 9))
+    # operands the scan does not take itself
+    run(100.0, np.array([1.0, -2.5, 0.0, -0.0, 5e-324, 1e-310, 3.0, -1e-3] * 20))
+    run(100.0, np.zeros(130))
+    run(-3.0, rng.random(70))
+    run(0.0, rng.random(70))
+    # random magnitudes across the whole exponent range below the running value
+    for trial in range(40):
+        r0 = float(2.0 ** rng.uniform(-20, 40))
+        x = r0 * 2.0 ** rng.uniform(-70, -1, 500) * (rng.random(500) < 0.8)
+        run(r0, x)
+
+
 def test_mixed_binding_and_not(amd):
     """some envs hit the budget, others do not, in the same launch"""
     N, K = 8, 64
