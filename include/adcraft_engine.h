@@ -461,7 +461,7 @@ int adc_debug_chain_device(int device_id, double r0, int64_t n, const double *x,
  * stopped, [3] for another reason (budget <= 0, a keyword-day above 2^22 cents in metric mode).  Test / measurement aid. */
 int adc_debug_walk_stats(adc_engine *e, int64_t stats[4], int reset);
 /* env-days k_tail_or_flag handed to k_step_rest_of_day at once, without the row kernel (a budget that ran out within the first
- * cells of the previous day), on the engine's device since the library was loaded (or the last reset).  Test / measurement aid. */
+ * cells of the previous day), by THIS engine since it was created (or the last call with reset != 0).  Test / measurement aid. */
 int adc_debug_direct_days(adc_engine *e, int64_t *env_days, int reset);
 int adc_debug_win_brackets_device(int device_id, int64_t n, const float *bid, const float *cost_loc, const float *cost_scale,
                                   const float *buyside_ctr, uint32_t *out8);

@@ -340,3 +340,17 @@ def test_win_brackets_enclose_the_exact_intervals():
     assert L.adc_auction_word_intervals(0.7, 0.55, 0.08, 0.5, x) == 0
     assert out[0] <= x[0] <= out[4] and out[4] + out[5] <= x[0] + x[1] <= out[0] + out[1]
     assert 0 < (out[1] - out[5]) < 2**18 and out[5] > 2**28
+
+
+def test_integration_doc_quotes_the_headers_abi_version():
+    """INTEGRATION.md's ctypes stub asserts an ABI version: it must be the header's (round 4 shipped a stub that asserted 3 against a
+    library of 4), and the versions the Python binding expects must be the header's too"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "adcraft_engine.h")).read()
+    abi = int(re.search(r"#define ADC_ABI_VERSION (\d+)", header).group(1))
+    rev = int(re.search(r"#define ADC_STREAM_REVISION (\d+)", header).group(1))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    quoted = [int(x) for x in re.findall(r"adc_abi_version\(\) == (\d+)", doc)]
+    assert quoted and all(q == abi for q in quoted)
+    assert (_ffi.ABI_VERSION, _ffi.STREAM_REVISION) == (abi, rev)

@@ -1,10 +1,13 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- bash tools/final_suite_r05.sh): the round's final numbers into gpurun_out/final5/.
 # Copy what is to be judged into profiles/ afterwards (tools/copy_final_r05.sh: r05_final_*).
+# In parts (a gpurun call is limited to 20 minutes): bash tools/final_suite_r05.sh bench | timings | soaks1 | soaks2
 set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/final5
-rm -rf $OUT; mkdir -p $OUT
+mkdir -p $OUT
+PART=${1:-bench}
+if [ $PART = bench ]; then
 # the driver's command (its shape: --steps 20 --warmup 5), the default invocation, then the same workloads alone under the kernel trace
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_shape.json 2> $OUT/bench.err || exit 1
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2>> $OUT/bench.err || exit 1
@@ -16,6 +19,8 @@ echo "kernel traces done"
 for c in cfg2 cfg3 cfg4 cfg5; do timeout -k 10 400 python3 tools/pmc_collect.py $c $OUT/pmc > $OUT/pmc_$c.log 2>&1 || exit 1; done
 rm -rf $OUT/pmc/*_fetch $OUT/pmc/*_write $OUT/pmc/*_sq $OUT/kt_cfg2/*kernel_trace.csv $OUT/kt_cfg3/*kernel_trace.csv $OUT/kt_cfg4/*kernel_trace.csv
 echo "pmc done"
+fi
+if [ $PART = timings ]; then
 for b in 1000 10 1; do timeout -k 10 200 python3 bench.py --config cfg2 --budget $b --no-cpu-baseline > $OUT/bench_budget$b.json 2>> $OUT/bench.err || exit 1; done
 timeout -k 10 200 python3 tools/exp_binding.py > $OUT/binding.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/exp_binding_wide.py > $OUT/binding_wide.txt 2>&1 || exit 1
@@ -30,16 +35,22 @@ ADCRAFT_FAST_VARIANT=2 timeout -k 10 200 python3 tools/exp_sparse_floor.py 40 > 
 timeout -k 10 200 python3 tools/measure_keygen.py > $OUT/keygen.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_vector_env.py > $OUT/vector_env.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_small_env.py > $OUT/small_env.txt 2>&1 || exit 1
+for shape in "2048 1024 4000" "2048 1024 40" "4096 512 4000" "4096 512 40"; do bash tools/kt_shape.sh $shape >> $OUT/kernel_stats_wide_binding.txt 2>&1 || exit 1; done
+for b in 1000 10; do ADCRAFT_CLICK_WALK=0 bash tools/kt_budget.sh $b > /dev/null 2>&1 || exit 1; cp gpurun_out/kt_b$b/kt_kernel_stats.csv $OUT/kernel_stats_budget$b.csv; done
 echo "timings done"
+fi
+if [ $PART = soaks1 ]; then
 timeout -k 10 300 python3 tools/soak_parity.py 100 401 > $OUT/soak_implicit.txt 2>&1 || exit 1
 ADCRAFT_FAST_VARIANT=2 ADCRAFT_FAST_TILE_KW=256 timeout -k 10 300 python3 tools/soak_parity.py 80 404 > $OUT/soak_implicit_sparse_kernel.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 80 402 explicit > $OUT/soak_explicit.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 80 403 general > $OUT/soak_general.txt 2>&1 || exit 1
+for f in $OUT/soak_*.txt; do echo "$f: $(tail -n1 $f)"; done
+fi
+if [ $PART = soaks2 ]; then
 ADCRAFT_GENERAL_SMALL=0 timeout -k 10 300 python3 tools/soak_parity.py 60 408 general > $OUT/soak_general_lane_per_keyword.txt 2>&1 || exit 1
 ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 60 405 > $OUT/soak_implicit_rest_pair.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 60 409 lists > $OUT/soak_implicit_lists.txt 2>&1 || exit 1
 ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 60 410 small > $OUT/soak_implicit_at_once.txt 2>&1 || exit 1
-for shape in "2048 1024 4000" "2048 1024 40" "4096 512 4000" "4096 512 40"; do bash tools/kt_shape.sh $shape >> $OUT/kernel_stats_wide_binding.txt 2>&1 || exit 1; done
-for b in 1000 10; do ADCRAFT_CLICK_WALK=0 bash tools/kt_budget.sh $b > /dev/null 2>&1 || exit 1; cp gpurun_out/kt_b$b/kt_kernel_stats.csv $OUT/kernel_stats_budget$b.csv; done
 for f in $OUT/soak_*.txt; do echo "$f: $(tail -n1 $f)"; done
-echo done
+fi
+echo "part $PART done"
