@@ -165,6 +165,8 @@ def lib():
         "adc_debug_walk_stats": ([vp, vp, C.c_int], C.c_int),
         "adc_debug_direct_days": ([vp, vp, C.c_int], C.c_int),
         "adc_debug_chain_device": ([C.c_int, f64, i64, vp, vp], C.c_int),
+        "adc_engine_env_groups": ([vp, vp], C.c_int),
+        "adc_engine_set_env_groups": ([vp, C.c_int32], C.c_int),
         "adc_comm_get_unique_id": ([vp], C.c_int),
         "adc_engine_comm_init": ([vp, vp, i32, i32], C.c_int),
         "adc_engine_comm_destroy": ([vp], C.c_int),

@@ -357,6 +357,16 @@ class StepEngine:
         check(self._lib.adc_debug_direct_days(self._h, out.ctypes.data, 1 if reset else 0))
         return int(out[0])
 
+    def env_groups(self):
+        """how many env groups (streams) the last IMPLICIT step ran as (adc_engine_env_groups); scheduling only"""
+        n = C.c_int32(1)
+        check(self._lib.adc_engine_env_groups(self._h, C.byref(n)))
+        return n.value
+
+    def set_env_groups(self, groups):
+        """0: the engine chooses how many env groups a step runs as; 1..4: that many (adc_engine_set_env_groups)"""
+        check(self._lib.adc_engine_set_env_groups(self._h, int(groups)))
+
     def step_kernel_name(self):
         """the first-pass kernel of the last step (the one profile_read()'s first duration times)"""
         return self._lib.adc_engine_step_kernel_name(self._h).decode()

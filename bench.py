@@ -150,6 +150,16 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         eng.synchronize()
         spin_steps += 16
     barrier()
+    # where the engine runs the step as env groups on several streams, the same K steps as ONE group (the schedule the kernel
+    # times below are taken on): the figure the full-batch kernel's duration is to be read against
+    eng.set_env_groups(1)
+    barrier()
+    t_g = time.perf_counter()
+    for _ in range(steps):
+        eng.step_device()
+    barrier()
+    one_group_ms = (time.perf_counter() - t_g) / steps * 1e3
+    eng.set_env_groups(int(os.environ.get("ADCRAFT_STREAM_GROUPS", "0")))      # (back to the engine's choice, or the environment's)
     # kernel times: a separate, UNTIMED pass of the same length with HIP events around every step (four event records per step
     # keep a step's small tail kernels from overlapping the next step's launch: ~16 us of every step) ...
     eng.profile_enable(True, every=1)
@@ -175,6 +185,7 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
             collective_host_s += time.perf_counter() - tc
     barrier()
     elapsed = time.perf_counter() - t0
+    groups = eng.env_groups()                    # how the engine scheduled the timed steps (env groups on their own streams)
     region_gpu_ms = eng.region_end()
     records_in_timed_region = eng.profile_records() - records_before
     coll_calls, coll_ms_local, coll_ms_allreduce = eng.comm_stats(reset=True)
@@ -201,6 +212,13 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         "envs_per_gpu": N, "keywords": K,
         "clock_spin_steps": spin_steps,
         "ms_per_step_before_clock_spin": unspun_ms,
+        "env_groups": {"timed_region": groups, "profiled_pass": 1, "ms_per_step_as_one_group": one_group_ms,
+                       "note": (f"the timed steps ran as {groups} contiguous env groups of {N // groups} envs, each on its own HIP stream "
+                                "(adc_engine_env_groups): one group's small kernels run under another's keyword-parallel pass and consecutive "
+                                "steps of different groups overlap, so ms_per_step can be BELOW roofline.kernel_ms - that is the duration "
+                                "of the kernel launched over all envs at once, as the profiled pass (always one group) launches it. "
+                                "ADCRAFT_STREAM_GROUPS=1 runs the timed region the same way") if groups > 1 else
+                               "one launch per kernel over all envs, in the timed region as in the profiled pass"},
         "timed_region": {"host_ms_per_step": own_elapsed / steps * 1e3, "gpu_ms_per_step": region_gpu_ms / steps,
                          "method": "host clock between two barriers (the contract's figure) | one HIP event pair on the engine's stream "
                                    "around the same region"},
@@ -208,7 +226,8 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": notes.get("hbm_bytes_per_launch"),
                      "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else notes.get("stale")),
-                     "kernel": step_kernel if dom == 0 else KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps,
+                     "kernel": step_kernel if dom == 0 else KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps * groups,
+                     "envs_per_launch": {"profiled_pass": N, "timed_region": N // groups},
                      "event_records_in_timed_region": int(records_in_timed_region),
                      "kernel_ms_method": f"HIP events on the engine's stream around every step of a separate, untimed pass of {steps} steps "
                                          "run between the warm-up and the timed region (same process, same state; the timed region itself "
@@ -340,7 +359,7 @@ def run_rank(args):
         r = run_config(c, args, rank, world, local_rank, max(60 if c == "cfg4" else 50, min(args.steps, 100)), max(10, min(args.warmup, 20)),
                        with_cpu_baseline=False, collective_alone=(c == "cfg4" and not args.no_collective_alone))
         also[c] = {k: r[k] for k in ("value", "ms_per_step", "steps", "workload", "roofline", "episode_metric", "collective", "timed_region",
-                                     "clock_spin_steps", "ms_per_step_before_clock_spin", "ms_per_step_by_rank") if k in r}
+                                     "clock_spin_steps", "ms_per_step_before_clock_spin", "ms_per_step_by_rank", "env_groups") if k in r}
         if "roofline_valu" in r:
             also[c]["roofline_valu"] = r["roofline_valu"]
     if rank == 0:
@@ -361,7 +380,7 @@ def run_rank(args):
             "env_steps_per_s": main["env_steps_per_s"],
             "roofline": main["roofline"],
         }
-        for k in ("timed_region", "clock_spin_steps", "ms_per_step_before_clock_spin", "ms_per_step_by_rank", "collective", "roofline_valu", "episode_metric", "cpu_baseline"):
+        for k in ("timed_region", "clock_spin_steps", "ms_per_step_before_clock_spin", "env_groups", "ms_per_step_by_rank", "collective", "roofline_valu", "episode_metric", "cpu_baseline"):
             if k in main:
                 line[k] = main[k]
         if also:

@@ -283,6 +283,17 @@ int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
  * checked against */
 int adc_engine_region_begin(adc_engine *e);
 int adc_engine_region_end(adc_engine *e, double *gpu_ms);
+/* how many ENV GROUPS the last IMPLICIT step ran as (1: all envs as one launch per kernel on the engine's stream).  From 2048 envs on
+ * (up to 1024 keywords, dense keyword sets) a step runs as 4 contiguous env groups, each with its own view of the engine's arrays, its
+ * own lists and its own HIP stream: one group's small latency-bound kernels (step tail, budget-exact kernels) run under another's
+ * keyword-parallel pass, and with device-resident steps following each other (adc_engine_step_device) a group starts its next step
+ * while another finishes this one.  Scheduling only - results never depend on it.  The engine's stream is made to wait for the
+ * groups whenever anything else is enqueued on it (every other entry point; at once after adc_engine_stream has handed it out), so
+ * callers order their work behind a step exactly as before.  While profiling brackets kernels with events, a step is one group. */
+int adc_engine_env_groups(adc_engine *e, int32_t *groups);
+/* ... and fixes it: 0 = the engine chooses (the default), 1..4 = that many groups (capped by the env count; 1 is the one-stream
+ * schedule of earlier ABI versions).  ADCRAFT_STREAM_GROUPS in the environment sets the same thing at creation. */
+int adc_engine_set_env_groups(adc_engine *e, int32_t groups);
 /* name of the kernel the last step's first pass ran (the one kernel_ms_total[0] times).  IMPLICIT: "k_step_implicit_fast<false>"
  * (dense keyword sets, 256 keywords per workgroup), "k_step_implicit_fast<true>" (a handful of envs: narrow tiles), either with
  * ", lists" before the ">" once an env lists its clicked wins for k_step_click_walk ("k_step_implicit_fast<false, lists>"),

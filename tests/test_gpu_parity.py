@@ -307,6 +307,93 @@ def test_float_chain_by_integer_scan(amd):
         run(r0, x)
 
 
+@pytest.mark.parametrize("groups", ["2", "3", "4"])
+def test_env_groups_on_their_own_streams_change_nothing(amd, monkeypatch, groups):
+    """From 2048 envs on an IMPLICIT step runs as 2 or 4 env GROUPS - contiguous env ranges, each with its own view of the engine's
+    arrays, its own lists and counters, its own stream - so that one group's latency-bound kernels run under another's keyword-parallel
+    pass.  Scheduling only: forced here on a handful of envs (ADCRAFT_STREAM_GROUPS, uneven group sizes included), every path a step
+    can take gives the oracle's results - the budget-free pass (both kernels), budgets that bind (row kernel, rest-of-day pair,
+    at-once parking, click lists), drift, metric sums, auto-reset, host steps interleaved with device-resident ones, a profiled
+    stretch (one group while events bracket the kernels) in the middle."""
+    monkeypatch.setenv("ADCRAFT_STREAM_GROUPS", groups)
+    monkeypatch.setenv("ADCRAFT_REST_SPLIT", "1")
+    for case in ("dense", "sparse", "lists", "rest_pair", "at_once"):
+        N, K = (7, 256) if case != "sparse" else (5, 300)
+        if case == "lists":
+            monkeypatch.delenv("ADCRAFT_CLICK_WALK", raising=False)
+        elif case in ("rest_pair", "at_once"):
+            monkeypatch.setenv("ADCRAFT_CLICK_WALK", "0")
+        if case == "sparse":
+            monkeypatch.setenv("ADCRAFT_FAST_VARIANT", "2")
+            monkeypatch.setenv("ADCRAFT_FAST_TILE_KW", "256")
+            planes = H.implicit_params(N, K, seed=91, mean_volume=16, cvr=0.1, no_vol_prob=0.5)
+        else:
+            monkeypatch.delenv("ADCRAFT_FAST_VARIANT", raising=False)
+            monkeypatch.delenv("ADCRAFT_FAST_TILE_KW", raising=False)
+            planes = H.implicit_params(N, K, seed=92, mean_volume=40)
+        budgets = {"dense": [1e9, 1e9, 900.0, 1e9], "sparse": [1e9, 3.0, 3.0, 1e9], "lists": [900.0] * 5,
+                   "rest_pair": [700.0, 700.0, 40.0, 700.0, 1e9, 700.0], "at_once": [3.0, 3.0, 3.0, 3.0, 20.0, 3.0, 3.0]}[case]
+        e = amd.StepEngine(N, K, seed=23, drift_enabled=True, max_days=4, loss_threshold=1e9, auto_reset=True)
+        e.set_all_params(planes)
+        e.reset()
+        e.metrics_enable(True)
+        e.metrics_reset()
+        o = H.mirror_oracle(e, planes, drift_on=True, max_days=4, loss_threshold=1e9, auto_reset=True)
+        profit = np.zeros(K, np.int64)
+        for i, budget in enumerate(budgets):
+            bids = o.sample_bids(0.4, 1.2)
+            if i == 2:
+                e.profile_enable(True)
+            if i % 2 == 0:
+                got = e.step(bids, budget)
+            else:                                   # device-resident: the engine's own action stream (the oracle's sample_bids), fetched afterwards
+                e.sample_actions(0.4, 1.2, budget)
+                e.step_device()
+                got = e.fetch()
+            if i == 2:
+                e.profile_enable(False)
+            ref = o.step(bids, budget)
+            H.assert_step_equal(got, ref, implicit=True)
+            profit += (ref["revenue_cents"] - ref["cost_cents"]).sum(axis=0)
+        kp, sc = e.metrics_read()
+        assert np.array_equal(kp, profit) and sc[1] == len(budgets) * N
+        o.materialize_drift()
+        assert np.array_equal(e.get_all_params(), o.params)
+        e.close()
+
+
+def test_env_groups_at_the_size_the_engine_chooses_them(amd):
+    """2048 envs: the engine's own choice (4 groups for a dense keyword set, 1 for a sparse one, 1 while profiling) against the oracle -
+    budget-free and binding steps, device-resident steps following each other without a host call in between, then a fetch"""
+    N, K = 2048, 32
+    for mean_volume, want in ((40, 4), (8, 1)):
+        planes = H.implicit_params(N, K, seed=93, mean_volume=mean_volume)
+        e = amd.StepEngine(N, K, seed=29, drift_enabled=True)
+        e.set_all_params(planes)
+        e.reset()
+        o = H.mirror_oracle(e, planes, drift_on=True, threads=8)
+        for budget in (1e9, 12.0, 12.0):
+            bids = o.sample_bids(0.3, 1.0)
+            H.assert_step_equal(e.step(bids, budget), o.step(bids, budget), implicit=True)
+            assert e.env_groups() == want
+        for budget in (12.0, 1e9, 12.0):        # device-resident, back to back: the groups run ahead of each other
+            e.sample_actions(0.3, 1.0, budget)
+            bids = o.sample_bids(0.3, 1.0)
+            for _ in range(3):                      # (the same bids three days running: nothing between the steps joins the groups)
+                ref = o.step(bids, budget)
+                e.step_device()
+            H.assert_step_equal(e.fetch(), ref, implicit=True)
+            assert e.env_groups() == want
+        e.profile_enable(True)
+        bids = o.sample_bids(0.3, 1.0)
+        H.assert_step_equal(e.step(bids, 12.0), o.step(bids, 12.0), implicit=True)
+        assert e.env_groups() == 1
+        e.profile_enable(False)
+        o.materialize_drift()
+        assert np.array_equal(e.get_all_params(), o.params)
+        e.close()
+
+
 def test_mixed_binding_and_not(amd):
     """some envs hit the budget, others do not, in the same launch"""
     N, K = 8, 64

@@ -13,11 +13,12 @@ timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_sha
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2>> $OUT/bench.err || exit 1
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg2 -o kt -- python3 bench.py --no-also --no-cpu-baseline > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/kt_cfg2.err || exit 1
+ADCRAFT_STREAM_GROUPS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg2_one_group -o kt -- python3 bench.py --no-also --no-cpu-baseline > $OUT/bench_cfg2_one_group_under_rocprof.json 2> $OUT/kt_cfg2_one_group.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg3 -o kt -- python3 bench.py --config cfg3 --no-cpu-baseline > $OUT/bench_cfg3_under_rocprof.json 2> $OUT/kt_cfg3.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg4 -o kt -- python3 bench.py --config cfg4 --no-cpu-baseline --steps 120 > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/kt_cfg4.err || exit 1
 echo "kernel traces done"
 for c in cfg2 cfg3 cfg4 cfg5; do timeout -k 10 400 python3 tools/pmc_collect.py $c $OUT/pmc > $OUT/pmc_$c.log 2>&1 || exit 1; done
-rm -rf $OUT/pmc/*_fetch $OUT/pmc/*_write $OUT/pmc/*_sq $OUT/kt_cfg2/*kernel_trace.csv $OUT/kt_cfg3/*kernel_trace.csv $OUT/kt_cfg4/*kernel_trace.csv
+rm -rf $OUT/pmc/*_fetch $OUT/pmc/*_write $OUT/pmc/*_sq $OUT/kt_cfg2/*kernel_trace.csv $OUT/kt_cfg2_one_group/*kernel_trace.csv $OUT/kt_cfg3/*kernel_trace.csv $OUT/kt_cfg4/*kernel_trace.csv
 echo "pmc done"
 fi
 if [ $PART = timings ]; then
@@ -51,6 +52,7 @@ ADCRAFT_GENERAL_SMALL=0 timeout -k 10 300 python3 tools/soak_parity.py 60 408 ge
 ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 60 405 > $OUT/soak_implicit_rest_pair.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/soak_parity.py 60 409 lists > $OUT/soak_implicit_lists.txt 2>&1 || exit 1
 ADCRAFT_REST_SPLIT=1 ADCRAFT_CLICK_WALK=0 timeout -k 10 300 python3 tools/soak_parity.py 60 410 small > $OUT/soak_implicit_at_once.txt 2>&1 || exit 1
+ADCRAFT_STREAM_GROUPS=3 timeout -k 10 300 python3 tools/soak_parity.py 50 411 > $OUT/soak_implicit_env_groups.txt 2>&1 || exit 1
 for f in $OUT/soak_*.txt; do echo "$f: $(tail -n1 $f)"; done
 fi
 echo "part $PART done"
