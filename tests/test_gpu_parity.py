@@ -362,6 +362,57 @@ def test_env_groups_on_their_own_streams_change_nothing(amd, monkeypatch, groups
         e.close()
 
 
+@pytest.mark.parametrize("model,K,groups", [(1, 96, 3), (1, 700, 4), (2, 300, 2), (2, 64, 4)])
+def test_env_groups_of_the_float_money_models(amd, model, K, groups):
+    """the same for ExplicitKeyword and the default ImplicitKeyword (their steps are chains of one-workgroup-per-env kernels): forced
+    on a handful of envs, uneven groups, budgets that bind early, late and not at all, drift, metric sums, host steps and device-
+    resident ones, a profiled step in between"""
+    N = 7
+    if model == 1:
+        planes = H.explicit_params(N, K, seed=61)
+        extra = {}
+        lo, hi, budgets = 0.05, 2.0, (K * 1.5, K * 1.5, 1e9, K * 0.1, 1e9, K * 4.0)
+    else:
+        rng = np.random.default_rng(62)
+        planes = np.stack([rng.integers(0, 60, (N, K)), rng.random((N, K)) * 6, rng.uniform(0.0, 0.3, (N, K)), rng.uniform(0.05, 0.15, (N, K)),
+                           rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.2, 0.9, (N, K)), rng.uniform(0.3, 1.5, (N, K)),
+                           rng.uniform(0.02, 0.3, (N, K))]).astype(np.float32)
+        extra = dict(max_bidders=30, participation_rate=0.6, num_winners=1)
+        lo, hi, budgets = 0.05, 0.5, (K * 0.05, K * 0.05, 1e9, K * 0.004, 1e9, K * 0.2)
+    e = amd.StepEngine(N, K, model=model, seed=19, drift_enabled=True)
+    if model == 2:
+        e.set_general_model(30, 0.6, 1)
+    e.set_env_groups(groups)
+    e.set_all_params(planes)
+    e.reset()
+    e.metrics_enable(True)
+    e.metrics_reset()
+    o = H.mirror_oracle(e, planes, drift_on=True, **extra)
+    bound = 0
+    for i, b in enumerate(budgets):
+        bids = o.sample_bids(lo, hi)
+        if i == 3:
+            e.profile_enable(True)
+        if i % 2 == 0:
+            got = e.step(bids, b)
+        else:
+            e.sample_actions(lo, hi, b)
+            e.step_device()
+            got = e.fetch()
+        assert e.env_groups() == (1 if i == 3 else groups)
+        if i == 3:
+            e.profile_enable(False)
+        ref = o.step(bids, b)
+        H.assert_step_equal(got, ref, implicit=False)
+        bound += int((ref["cost"].astype(np.float64).sum(axis=1) >= 0.98 * b).sum())
+    assert bound >= N          # the budgets really bound
+    _, sc = e.metrics_read()
+    assert sc[1] == len(budgets) * N
+    o.materialize_drift()
+    assert np.array_equal(e.get_all_params(), o.params)
+    e.close()
+
+
 def test_env_groups_at_the_size_the_engine_chooses_them(amd):
     """2048 envs: the engine's own choice (4 groups for a dense keyword set, 1 for a sparse one, 1 while profiling) against the oracle -
     budget-free and binding steps, device-resident steps following each other without a host call in between, then a fetch"""
