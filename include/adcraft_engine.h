@@ -284,8 +284,8 @@ int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
 int adc_engine_region_begin(adc_engine *e);
 int adc_engine_region_end(adc_engine *e, double *gpu_ms);
 /* how many ENV GROUPS the last step ran as (1: all envs as one launch per kernel on the engine's stream).  From 2048 envs on (up to
- * 1024 keywords; not for sparse IMPLICIT keyword sets, nor the default ImplicitKeyword beyond 512 keywords, which measured slower) a
- * step of any model runs as 4 contiguous env groups, each with its own view of the engine's arrays, its
+ * 1024 keywords; not the default ImplicitKeyword beyond 512 keywords, which measured slower) a step of any model runs as 4
+ * contiguous env groups (2 for sparse IMPLICIT keyword sets), each with its own view of the engine's arrays, its
  * own lists and its own HIP stream: one group's small latency-bound kernels (step tail, budget-exact kernels) run under another's
  * keyword-parallel pass, and with device-resident steps following each other (adc_engine_step_device) a group starts its next step
  * while another finishes this one.  Scheduling only - results never depend on it.  The engine's stream is made to wait for the

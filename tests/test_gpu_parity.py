@@ -414,10 +414,10 @@ def test_env_groups_of_the_float_money_models(amd, model, K, groups):
 
 
 def test_env_groups_at_the_size_the_engine_chooses_them(amd):
-    """2048 envs: the engine's own choice (4 groups for a dense keyword set, 1 for a sparse one, 1 while profiling) against the oracle -
+    """2048 envs: the engine's own choice (4 groups for a dense keyword set, 2 for a sparse one, 1 while profiling) against the oracle -
     budget-free and binding steps, device-resident steps following each other without a host call in between, then a fetch"""
     N, K = 2048, 32
-    for mean_volume, want in ((40, 4), (8, 1)):
+    for mean_volume, want in ((40, 4), (8, 2)):
         planes = H.implicit_params(N, K, seed=93, mean_volume=mean_volume)
         e = amd.StepEngine(N, K, seed=29, drift_enabled=True)
         e.set_all_params(planes)
