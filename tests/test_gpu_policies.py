@@ -213,6 +213,40 @@ def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
     assert 0.6 < np.median(runs[0][1]) < 1.4
 
 
+@pytest.mark.parametrize("policy", ["zero_margin", "oracle", "fixed"])
+def test_run_days_in_env_groups_equals_one_group(amd, policy):
+    """adc_engine_run_days with the step in env groups on their own streams: every day's policy kernels write the bids on the engine's
+    stream, so every day's groups have to wait for it - same trajectory as the one-stream schedule (which other tests pin to the oracle),
+    with and without the per-step ideal between the agent and the step"""
+    N, K, days = 9, 64, 14
+    planes = H.implicit_params(N, K, seed=95, mean_volume=30, cvr=0.6)
+    for curves in ((False, True) if policy == "zero_margin" else (policy == "oracle",)):
+        out = []
+        for groups in (1, 3):
+            e = amd.StepEngine(N, K, seed=41, drift_enabled=True, drift=(0.05, 0.05, 0.05), max_days=1 << 20, loss_threshold=1e12)
+            e.set_env_groups(groups)
+            e.set_all_params(planes)
+            e.reset()
+            e.metrics_enable(True)
+            if curves:
+                e.bid_curves_build(2048)
+            if policy == "zero_margin":
+                e.agent_init(1.0, np.arange(N, dtype=np.uint64))
+            else:
+                e.sample_actions(0.3, 1.0, 40.0)
+            e.run_days(policy, days, budget=40.0, graph=False)
+            assert e.env_groups() == groups
+            o = e.fetch()
+            kp, sc = e.metrics_read()
+            out.append((o, kp, sc, e.get_all_params(), e.get_actions()))
+            e.close()
+        (a, akp, asc, ap, aa), (b, bkp, bsc, bp, ba) = out
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (policy, curves, key)
+        assert np.array_equal(akp, bkp) and np.array_equal(asc, bsc) and np.array_equal(ap, bp)
+        assert np.array_equal(aa[0], ba[0]) and np.array_equal(aa[1], ba[1])
+
+
 @pytest.mark.parametrize("K", [1, 2, 33, 64, 1000, 4096])
 def test_device_median_matches_numpy_for_odd_even_and_padded_keyword_counts(amd, K):
     from adcraft_amd.closed_loop import run_baseline_episode

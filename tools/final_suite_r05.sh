@@ -8,6 +8,17 @@ OUT=gpurun_out/final5
 mkdir -p $OUT
 PART=${1:-bench}
 if [ $PART = bench ]; then
+# the PMC passes first (the bench lines print them only from a record with this build's source hash), then
+for c in cfg2 cfg3 cfg4 cfg5; do timeout -k 10 400 python3 tools/pmc_collect.py $c $OUT/pmc > $OUT/pmc_$c.log 2>&1 || exit 1; done
+python3 - <<'PY' || exit 1
+import json
+out = {}
+for c in ("cfg2", "cfg3", "cfg4", "cfg5"):
+    d = json.load(open(f"gpurun_out/final5/pmc/pmc_{c}.json"))
+    out.update(d if c in d else {c: d})
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)     # (on the box: the bench lines below then carry this build's counters)
+PY
+echo "pmc done"
 # the driver's command (its shape: --steps 20 --warmup 5), the default invocation, then the same workloads alone under the kernel trace
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_shape.json 2> $OUT/bench.err || exit 1
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2>> $OUT/bench.err || exit 1
@@ -17,9 +28,8 @@ ADCRAFT_STREAM_GROUPS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg3 -o kt -- python3 bench.py --config cfg3 --no-cpu-baseline > $OUT/bench_cfg3_under_rocprof.json 2> $OUT/kt_cfg3.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg4 -o kt -- python3 bench.py --config cfg4 --no-cpu-baseline --steps 120 > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/kt_cfg4.err || exit 1
 echo "kernel traces done"
-for c in cfg2 cfg3 cfg4 cfg5; do timeout -k 10 400 python3 tools/pmc_collect.py $c $OUT/pmc > $OUT/pmc_$c.log 2>&1 || exit 1; done
+
 rm -rf $OUT/pmc/*_fetch $OUT/pmc/*_write $OUT/pmc/*_sq $OUT/kt_cfg2/*kernel_trace.csv $OUT/kt_cfg2_one_group/*kernel_trace.csv $OUT/kt_cfg3/*kernel_trace.csv $OUT/kt_cfg4/*kernel_trace.csv
-echo "pmc done"
 fi
 if [ $PART = timings ]; then
 for b in 1000 10 1; do timeout -k 10 200 python3 bench.py --config cfg2 --budget $b --no-cpu-baseline > $OUT/bench_budget$b.json 2>> $OUT/bench.err || exit 1; done

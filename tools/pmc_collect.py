@@ -26,7 +26,8 @@ for name, counters in PASSES.items():
     cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "pmc", "--", "python3", "bench.py", "--config", cfg,
            "--steps", "12", "--warmup", "2", "--spin-seconds", "0", "--no-cpu-baseline"]
     with open(os.path.join(out, f"{cfg}_{name}.log"), "w") as log:
-        subprocess.check_call(cmd, stdout=log, stderr=subprocess.STDOUT)
+        # (one env group: every dispatch of the kernel is the full batch - the launch `roofline.kernel_ms` and the algorithmic bytes are per)
+        subprocess.check_call(cmd, stdout=log, stderr=subprocess.STDOUT, env=dict(os.environ, ADCRAFT_STREAM_GROUPS="1"))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_step_implicit" in r["Kernel_Name"]:
@@ -48,7 +49,7 @@ rec = {
              "valu_lane_instructions_per_auction": m["SQ_INSTS_VALU"] * 64.0 / auctions},
     "library_source_hash": hip_build.source_hash(),      # bench.py quotes these counters only for the build they were taken on
     "source_note": "builder-side rocprofv3 --pmc passes of `python3 bench.py --config " + cfg + "` on an MI355X (tools/pmc_collect.py, round 5); "
-                   "FETCH_SIZE doubled per the gfx950 correction; bench runs in metric mode (+8 B per keyword-step of accumulator traffic: a 32-bit word read and written)",
+                   "one env group (ADCRAFT_STREAM_GROUPS=1: every dispatch is the full batch); FETCH_SIZE doubled per the gfx950 correction; bench runs in metric mode (+8 B per keyword-step of accumulator traffic: a 32-bit word read and written)",
 }
 with open(os.path.join(out, f"pmc_{cfg}.json"), "w") as f:
     json.dump(rec, f, indent=1)
