@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <type_traits>
 #include <cmath>
 #include <cstdio>

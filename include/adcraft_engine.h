@@ -290,7 +290,9 @@ int adc_engine_region_end(adc_engine *e, double *gpu_ms);
  * keyword-parallel pass, and with device-resident steps following each other (adc_engine_step_device) a group starts its next step
  * while another finishes this one.  Scheduling only - results never depend on it.  The engine's stream is made to wait for the
  * groups whenever anything else is enqueued on it (every other entry point; at once after adc_engine_stream has handed it out), so
- * callers order their work behind a step exactly as before.  While profiling brackets kernels with events, a step is one group. */
+ * callers order their work behind a step exactly as before.  While profiling brackets kernels with events, a step is one group.
+ * The first grouped step of an engine picks the groups' streams - one per hardware queue, found by a 150 us spin kernel on pairs of
+ * candidate streams, because two groups on one queue would run one after the other: 15 to 50 ms, once. */
 int adc_engine_env_groups(adc_engine *e, int32_t *groups);
 /* ... and fixes it: 0 = the engine chooses (the default), 1..4 = that many groups (capped by the env count; 1 is the one-stream
  * schedule of earlier ABI versions).  ADCRAFT_STREAM_GROUPS in the environment sets the same thing at creation. */
