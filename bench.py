@@ -213,7 +213,7 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
         "clock_spin_steps": spin_steps,
         "ms_per_step_before_clock_spin": unspun_ms,
         "env_groups": {"timed_region": groups, "profiled_pass": 1, "ms_per_step_as_one_group": one_group_ms,
-                       "note": (f"the timed steps ran as {groups} contiguous env groups of {N // groups} envs, each on its own HIP stream "
+                       "note": (f"the timed steps (all but the first, which follows a barrier) ran as {groups} contiguous env groups of {N // groups} envs, each on its own HIP stream "
                                 "(adc_engine_env_groups): one group's small kernels run under another's keyword-parallel pass and consecutive "
                                 "steps of different groups overlap, so ms_per_step can be BELOW roofline.kernel_ms - that is the duration "
                                 "of the kernel launched over all envs at once, as the profiled pass (always one group) launches it. "
@@ -226,7 +226,7 @@ def run_config(cfg_name, args, rank, world, local_rank, steps, warmup, with_cpu_
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": notes.get("hbm_bytes_per_launch"),
                      "traffic_source": (notes.get("source_note") if notes.get("hbm_bytes_per_launch") else notes.get("stale")),
-                     "kernel": step_kernel if dom == 0 else KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps * groups,
+                     "kernel": step_kernel if dom == 0 else KERNEL_NAMES[dom], "kernel_ms": k_ms, "launches": int(launches), "launches_in_timed_region": steps if groups == 1 else 1 + (steps - 1) * groups,
                      "envs_per_launch": {"profiled_pass": N, "timed_region": N // groups},
                      "event_records_in_timed_region": int(records_in_timed_region),
                      "kernel_ms_method": f"HIP events on the engine's stream around every step of a separate, untimed pass of {steps} steps "

@@ -54,7 +54,7 @@ def _kernel_time_fits_the_step(d):
     way by more than noise; a step run as env groups on several streams may be shorter than that, and the line says so"""
     r, g = d["roofline"], d["env_groups"]
     assert g["profiled_pass"] == 1 and r["envs_per_launch"]["timed_region"] * g["timed_region"] == r["envs_per_launch"]["profiled_pass"]
-    assert r["launches_in_timed_region"] == d["steps"] * g["timed_region"]
+    assert r["launches_in_timed_region"] == (d["steps"] if g["timed_region"] == 1 else 1 + (d["steps"] - 1) * g["timed_region"])
     if g["timed_region"] == 1:
         assert r["kernel_ms"] <= d["ms_per_step"] * 1.05
     else:
@@ -68,7 +68,7 @@ def test_driver_shaped_run_times_a_region_without_event_records():
     d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-also")
     r = d["roofline"]
     assert d["steps"] == 20 and d["warmup"] == 5
-    assert r["launches_in_timed_region"] == 20 * d["env_groups"]["timed_region"] and r["event_records_in_timed_region"] == 0 and r["launches"] == 20
+    assert r["launches_in_timed_region"] == 1 + 19 * d["env_groups"]["timed_region"] and r["event_records_in_timed_region"] == 0 and r["launches"] == 20
     assert "untimed pass" in r["kernel_ms_method"]
     _kernel_time_fits_the_step(d)
 

@@ -4,6 +4,8 @@ Bit-exact for every integer (impressions, clicks, conversions, days, flags) and 
 (integer cents on both sides; the float32 dollars the kernels store are compared against the
 identically rounded oracle cents; f64 reward / cumulative profit compared bitwise).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -413,9 +415,41 @@ def test_env_groups_of_the_float_money_models(amd, model, K, groups):
     e.close()
 
 
+@pytest.mark.parametrize("queues", ["1", "2"])
+def test_env_groups_with_fewer_hardware_queues(queues):
+    """the groups' streams are probed: with the runtime limited to one or two hardware queues (GPU_MAX_HW_QUEUES, read when the process
+    initialises HIP - hence a child process) the engine finds one or two streams that overlap and runs that many groups, not four on
+    shared queues; results as ever"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.')\n"
+        "from tests import helpers as H\n"
+        "from adcraft_amd.engine import StepEngine\n"
+        "N, K = 9, 64\n"
+        "planes = H.implicit_params(N, K, seed=97, mean_volume=30)\n"
+        "out = []\n"
+        "for groups in (1, 4):\n"
+        "    e = StepEngine(N, K, seed=43, drift_enabled=True)\n"
+        "    e.set_env_groups(groups); e.set_all_params(planes); e.reset()\n"
+        "    e.sample_actions(0.3, 1.0, 25.0)\n"
+        "    for _ in range(5): e.step_device()\n"
+        "    o = e.fetch(); out.append((o, e.get_all_params(), e.env_groups())); e.close()\n"
+        "(a, ap, ag), (b, bp, bg) = out\n"
+        "assert all(np.array_equal(a[k], b[k]) for k in a) and np.array_equal(ap, bp)\n"
+        "print('GROUPS', ag, bg)\n")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues)
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith("GROUPS")][-1].split()
+    assert got[1] == "1" and 1 <= int(got[2]) <= int(queues), r.stdout
+
+
 def test_env_groups_at_the_size_the_engine_chooses_them(amd):
-    """2048 envs: the engine's own choice (4 groups for a dense keyword set, 2 for a sparse one, 1 while profiling) against the oracle -
-    budget-free and binding steps, device-resident steps following each other without a host call in between, then a fetch"""
+    """2048 envs: the engine's own choice against the oracle.  Groups are for CHAINED device-resident steps only (a step that follows a
+    step with no other call in between: 4 groups for a dense keyword set, 2 for a sparse one); a step behind any other call - a host
+    step, new actions, a fetch - and a profiled step run as one group.  Budget-free and binding steps, then a fetch"""
     N, K = 2048, 32
     for mean_volume, want in ((40, 4), (8, 2)):
         planes = H.implicit_params(N, K, seed=93, mean_volume=mean_volume)
@@ -426,15 +460,18 @@ def test_env_groups_at_the_size_the_engine_chooses_them(amd):
         for budget in (1e9, 12.0, 12.0):
             bids = o.sample_bids(0.3, 1.0)
             H.assert_step_equal(e.step(bids, budget), o.step(bids, budget), implicit=True)
-            assert e.env_groups() == want
+            assert e.env_groups() == 1                   # (a host step is joined at once: one group)
         for budget in (12.0, 1e9, 12.0):        # device-resident, back to back: the groups run ahead of each other
             e.sample_actions(0.3, 1.0, budget)
             bids = o.sample_bids(0.3, 1.0)
-            for _ in range(3):                      # (the same bids three days running: nothing between the steps joins the groups)
+            for _ in range(4):                      # (the same bids four days running: the first step behind sample_actions is one group, the chain behind it is grouped)
                 ref = o.step(bids, budget)
                 e.step_device()
-            H.assert_step_equal(e.fetch(), ref, implicit=True)
             assert e.env_groups() == want
+            H.assert_step_equal(e.fetch(), ref, implicit=True)
+            e.step_device()
+            assert e.env_groups() == 1                   # (behind the fetch)
+            o.step(bids, budget)
         e.profile_enable(True)
         bids = o.sample_bids(0.3, 1.0)
         H.assert_step_equal(e.step(bids, 12.0), o.step(bids, 12.0), implicit=True)
