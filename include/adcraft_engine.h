@@ -283,16 +283,20 @@ int adc_engine_profile_records(adc_engine *e, int64_t *event_records);
  * checked against */
 int adc_engine_region_begin(adc_engine *e);
 int adc_engine_region_end(adc_engine *e, double *gpu_ms);
-/* how many ENV GROUPS the last step ran as (1: all envs as one launch per kernel on the engine's stream).  From 2048 envs on (up to
- * 1024 keywords; not the default ImplicitKeyword beyond 512 keywords, which measured slower) a step of any model runs as 4
- * contiguous env groups (2 for sparse IMPLICIT keyword sets), each with its own view of the engine's arrays, its
- * own lists and its own HIP stream: one group's small latency-bound kernels (step tail, budget-exact kernels) run under another's
- * keyword-parallel pass, and with device-resident steps following each other (adc_engine_step_device) a group starts its next step
- * while another finishes this one.  Scheduling only - results never depend on it.  The engine's stream is made to wait for the
- * groups whenever anything else is enqueued on it (every other entry point; at once after adc_engine_stream has handed it out), so
- * callers order their work behind a step exactly as before.  While profiling brackets kernels with events, a step is one group.
- * The first grouped step of an engine picks the groups' streams - one per hardware queue, found by a 150 us spin kernel on pairs of
- * candidate streams, because two groups on one queue would run one after the other: 15 to 50 ms, once. */
+/* how many ENV GROUPS the last step ran as (1: all envs as one launch per kernel on the engine's stream).  A CHAIN of device-resident
+ * steps - adc_engine_step_device following adc_engine_step_device, with nothing between them but the device-side calls that touch
+ * every env on its own: adc_engine_agent_step, adc_engine_ideal_step without host outputs, adc_engine_policy_oracle,
+ * adc_engine_sample_actions; adc_engine_run_days is such a chain - of an engine with 2048 envs or more (up to 1024 keywords; not the
+ * default ImplicitKeyword beyond 512 keywords, nor a budget-free IMPLICIT batch of 16 rounds of workgroups or more, which measured
+ * slower) runs as 4 contiguous env groups (2 for sparse IMPLICIT keyword sets), each with its own view of the engine's arrays, its
+ * own lists and its own HIP stream: the tail of one group's launch and its small latency-bound kernels (step tail, budget-exact
+ * kernels, the per-step ideal) run under another group's keyword-parallel pass, and a group starts its next day while another
+ * finishes this one.  Scheduling only - results never depend on it.  Any other call ends the chain: it first makes the engine's
+ * stream wait for the groups, so callers order their work behind a step exactly as before, and the step behind it runs as one group
+ * (forking and joining the groups costs more than the overlap inside a single step returns).  After adc_engine_stream has handed the
+ * stream out, and while profiling brackets kernels with events, every step is one group.  The first grouped step of an engine picks
+ * the groups' streams - one per hardware queue, found by a 150 us spin kernel on pairs of candidate streams, because two groups on
+ * one queue would run one after the other: 15 to 50 ms, once. */
 int adc_engine_env_groups(adc_engine *e, int32_t *groups);
 /* ... and fixes it: 0 = the engine chooses (the default), 1..4 = that many groups (capped by the env count; 1 is the one-stream
  * schedule of earlier ABI versions).  ADCRAFT_STREAM_GROUPS in the environment sets the same thing at creation. */

@@ -213,6 +213,48 @@ def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
     assert 0.6 < np.median(runs[0][1]) < 1.4
 
 
+def test_policy_calls_between_chained_steps_run_group_by_group(amd):
+    """agent_step / ideal_step(fetch=False) / policy_oracle / sample_actions between two device-resident steps do not end a chain: while
+    the steps run as env groups they are launched per group on the groups' streams (no fork, no join).  Same trajectory, agent state,
+    ideal sums and drifted parameters as the one-stream schedule; a fetch in the middle (which joins) changes nothing either"""
+    N, K = 9, 64
+    planes = H.implicit_params(N, K, seed=96, mean_volume=30, cvr=0.6)
+    out = []
+    for groups in (1, 3):
+        e = amd.StepEngine(N, K, seed=45, drift_enabled=True, drift=(0.05, 0.05, 0.05), max_days=1 << 20, loss_threshold=1e12)
+        e.set_env_groups(groups)
+        e.set_all_params(planes)
+        e.reset()
+        e.metrics_enable(True)
+        e.bid_curves_build(2048)
+        e.agent_init(1.0, np.arange(N, dtype=np.uint64))
+        for day in range(12):
+            if day < 6:
+                e.agent_step(30.0)
+                e.ideal_step(fetch=False)
+            elif day < 9:
+                e.ideal_step(fetch=False)
+                e.policy_oracle(30.0)
+            else:
+                e.sample_actions(0.3, 1.0, 30.0)
+            e.step_device()
+            if day == 4:
+                mid = e.fetch()
+        assert e.env_groups() == groups
+        o = e.fetch()
+        st = e.agent_state()
+        profit, ideal, ideal_pos = e.metrics_read_nk()
+        out.append((o, mid, st, profit, ideal, ideal_pos, e.get_all_params(), e.get_actions()))
+        e.close()
+    a, b = out
+    for i in (0, 1, 2):
+        for key in a[i]:
+            assert np.array_equal(a[i][key], b[i][key], equal_nan=True), (i, key)
+    for i in (3, 4, 5, 6):
+        assert np.array_equal(a[i], b[i]), i
+    assert np.array_equal(a[7][0], b[7][0]) and np.array_equal(a[7][1], b[7][1])
+
+
 @pytest.mark.parametrize("policy", ["zero_margin", "oracle", "fixed"])
 def test_run_days_in_env_groups_equals_one_group(amd, policy):
     """adc_engine_run_days with the step in env groups on their own streams: every day's policy kernels write the bids on the engine's
