@@ -398,7 +398,8 @@ int adc_engine_get_actions(adc_engine *e, float *bids_nk, float *budget_n);
  * (FIXED_ACTIONS: whatever the action buffers hold; ZERO_MARGIN: adc_engine_agent_step, plus adc_engine_ideal_step when
  * curves are built; ORACLE: adc_engine_ideal_step + adc_engine_policy_oracle), then the env steps.  Asynchronous on
  * the engine's stream.  adc_engine_day_graph_enable(e, 1) makes it replay pairs of days from a captured hipGraph
- * (same results; measured no faster on MI355X - the dependent kernels of a day are latency-, not launch-bound). */
+ * (same results; measured no faster on MI355X - the dependent kernels of a day are latency-, not launch-bound - and an engine
+ * whose chain of days runs as env groups, see adc_engine_env_groups, keeps the plain chain, which is the faster of the two). */
 enum adc_policy { ADC_POLICY_FIXED_ACTIONS = 0, ADC_POLICY_ZERO_MARGIN = 1, ADC_POLICY_ORACLE = 2 };
 int adc_engine_run_days(adc_engine *e, int policy, int32_t days, float budget);
 int adc_engine_day_graph_enable(adc_engine *e, int enabled);
