@@ -46,8 +46,9 @@ ADCRAFT_FAST_VARIANT=2 timeout -k 10 200 python3 tools/exp_sparse_floor.py 40 > 
 timeout -k 10 200 python3 tools/measure_keygen.py > $OUT/keygen.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_vector_env.py > $OUT/vector_env.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/measure_small_env.py > $OUT/small_env.txt 2>&1 || exit 1
-for shape in "2048 1024 4000" "2048 1024 40" "4096 512 4000" "4096 512 40"; do bash tools/kt_shape.sh $shape >> $OUT/kernel_stats_wide_binding.txt 2>&1 || exit 1; done
-for b in 1000 10; do ADCRAFT_CLICK_WALK=0 bash tools/kt_budget.sh $b > /dev/null 2>&1 || exit 1; cp gpurun_out/kt_b$b/kt_kernel_stats.csv $OUT/kernel_stats_budget$b.csv; done
+# (kernel traces of binding steps as ONE env group: a launch's duration is then its own, not that of a launch sharing the chip with three others)
+for shape in "2048 1024 4000" "2048 1024 40" "4096 512 4000" "4096 512 40"; do ADCRAFT_STREAM_GROUPS=1 bash tools/kt_shape.sh $shape >> $OUT/kernel_stats_wide_binding.txt 2>&1 || exit 1; done
+for b in 1000 10; do ADCRAFT_STREAM_GROUPS=1 ADCRAFT_CLICK_WALK=0 bash tools/kt_budget.sh $b > /dev/null 2>&1 || exit 1; cp gpurun_out/kt_b$b/kt_kernel_stats.csv $OUT/kernel_stats_budget$b.csv; done
 echo "timings done"
 fi
 if [ $PART = soaks1 ]; then

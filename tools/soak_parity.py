@@ -20,7 +20,7 @@ general = len(sys.argv) > 3 and sys.argv[3] == "general"        # the default Im
 lists = len(sys.argv) > 3 and sys.argv[3] in ("lists", "small")
 small = len(sys.argv) > 3 and sys.argv[3] == "small"      # budgets that run out within the first cells of the day, day after day (hint 6: parked at once)
 t0 = time.time()
-cases = steps = reruns = 0
+cases = steps = reruns = at_once = 0
 last_report = t0
 while time.time() - t0 < budget_s:
     if time.time() - last_report > 60:          # (a silent GPU job is taken for a hung one)
@@ -89,7 +89,7 @@ while time.time() - t0 < budget_s:
         assert np.array_equal(e.get_all_params(), o.params)
     if lists:
         walk = e.walk_stats().tolist()          # (the device's counters: cumulative over the process)
-        at_once = e.direct_days()
+        at_once += e.direct_days()          # (a counter per engine)
     e.close()
     cases += 1
 if lists:

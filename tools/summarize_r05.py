@@ -23,10 +23,11 @@ L = ["# Round 5 - rocprofv3 evidence (1 x MI355X, builder-side gpurun box)\n",
      "workload alone), `... bench.py --config cfg3 --no-cpu-baseline`, `... --config cfg4` (the N > 1 workload's per-GPU shard, with its collective on a\n"
      "one-rank communicator); PMC: three separate `--pmc` passes per config (`tools/pmc_collect.py`: FETCH_SIZE, WRITE_SIZE, SQ counters), kernel-trace\n"
      "options only, one env group (every dispatch the full batch).\n",
-     "\n**Env groups.**  From 2048 envs on the engine launches a step as four env groups on four streams (two for sparse keyword sets;\n"
-     "`profiles/r05_stream_groups.txt`): in a trace of the default run the step kernel therefore appears four times per step at a quarter of the\n"
-     "batch (plus the full-batch launches of `bench.py`'s profiled and one-group passes), and its average duration there is that of a launch which\n"
-     "SHARES the chip with three others.  The table that `roofline.kernel_ms` is to be checked against is the second one, the same command under\n"
+     "\n**Env groups.**  From 2048 envs on the engine launches a CHAIN of device-resident steps as four env groups on four streams (two for sparse\n"
+     "keyword sets; `profiles/r05_stream_groups.txt`): in a trace of the default run the step kernel therefore appears four times per step at a quarter\n"
+     "of the batch (plus the full-batch launches of `bench.py`'s profiled and one-group passes and of the first step behind every barrier), and its\n"
+     "average duration there is that of a launch which SHARES the chip with three others.  `k_spin_ticks` (51 calls) is the one-time probe that picks\n"
+     "the groups' streams, one per hardware queue.  The table that `roofline.kernel_ms` is to be checked against is the second one, the same command under\n"
      "`ADCRAFT_STREAM_GROUPS=1`: every launch the full batch, alone on the chip.\n"]
 for name, c in (("cfg2 (4096 x 256, dense; the bench line's workload) - as the engine schedules it (4 env groups)", "cfg2"),
                 ("cfg2, the same command under ADCRAFT_STREAM_GROUPS=1 (one group: full-batch launches)", "cfg2_one_group"),
