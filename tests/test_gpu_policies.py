@@ -168,6 +168,43 @@ def test_contender_lists_give_the_full_scans_ideal_bit_for_bit(amd, monkeypatch,
     assert len({tuple(b.ravel()) for _, b in runs[0]}) > 1 or case == "extremes"      # the argmax really moved with the drift
 
 
+@pytest.mark.parametrize("n_samples,grid", [(2048, None), (40, None), (512, np.arange(0.01, 3.01, 0.01))])
+def test_contender_lists_hold_the_argmax_at_every_margin(amd, n_samples, grid):
+    """k_curve_contenders on its own (the envelope by wave-parallel elimination, the intervals, the scans that make their ends monotone):
+    for every keyword and a sweep of margins m, the FIRST argmax over the whole grid of ir_b (m - cpc_b) - numpy, float64, the reference's
+    expression (experiment_metrics.py:51-61) on the fetched curves - is a listed grid point whose margin interval holds m, the lists are
+    in grid order, and the points whose interval holds a margin are one contiguous run of the list"""
+    N, K = 6, 96
+    planes = H.implicit_params(N, K, seed=5, mean_volume=30, cvr=0.6)
+    planes[3, 1] *= np.linspace(0.1, 4.0, K).astype(np.float32)          # a spread of competitor laws
+    e = amd.StepEngine(N, K, seed=3)
+    e.set_all_params(planes)
+    e.reset()
+    e.bid_curves_build(n_samples, grid)
+    ir, cpc = e.bid_curves_fetch()
+    count, idx, iv = e.bid_curves_contenders()
+    e.close()
+    assert (count != 65535).all() and count.max() > 2
+    margins = np.concatenate([np.linspace(0.0, 3.5, 701), np.exp(np.linspace(np.log(1e-4), np.log(50.0), 300))])
+    checked = 0
+    for n in range(N):
+        for k in range(K):
+            c = int(count[n, k])
+            ids, lo, hi = idx[n, k, :c], iv[n, k, :c, 0].astype(np.float64), iv[n, k, :c, 1].astype(np.float64)
+            assert (np.diff(ids) > 0).all()
+            assert (np.diff(lo) >= 0).all() and (np.diff(hi) >= 0).all()          # monotone ends: the holders of a margin are contiguous
+            profit = ir[n, k][None, :] * (margins[:, None] - cpc[n, k][None, :])      # [margins, grid]
+            profit = np.where(profit > 0.0, profit, 0.0)
+            best = profit.argmax(axis=1)                                              # np.argmax: the first maximum
+            pos = profit.max(axis=1) > 0.0
+            for m, b in zip(margins[pos], best[pos]):
+                j = np.searchsorted(ids, b)
+                assert j < c and ids[j] == b, (n, k, m, b)
+                assert lo[j] <= m <= hi[j], (n, k, m, b, lo[j], hi[j])
+                checked += 1
+    assert checked > 10000
+
+
 def test_baseline_episode_metrics_match_a_step_by_step_run(amd):
     """run_baseline_episode (everything device-resident) vs the same loop done the notebooks' way: fetch every
     observation, stack kw_profits / ideal_profits, compute_AKNCP / compute_NCP (restatements pinned by G5)"""
