@@ -194,7 +194,7 @@ def test_contender_lists_hold_the_argmax_at_every_margin(amd, n_samples, grid):
                 continue
             ids, lo, hi = idx[n, k, :c], iv[n, k, :c, 0].astype(np.float64), iv[n, k, :c, 1].astype(np.float64)
             assert (np.diff(ids) > 0).all()
-            assert (np.diff(lo) >= 0).all() and (np.diff(hi) >= 0).all()          # monotone ends: the holders of a margin are contiguous
+            assert (lo[1:] >= lo[:-1]).all() and (hi[1:] >= hi[:-1]).all()        # monotone ends (infinite ones included): the holders of a margin are contiguous
             profit = ir[n, k][None, :] * (margins[:, None] - cpc[n, k][None, :])      # [margins, grid]
             profit = np.where(profit > 0.0, profit, 0.0)
             best = profit.argmax(axis=1)                                              # np.argmax: the first maximum
